@@ -1,0 +1,130 @@
+/*
+ * ultra_hip.h — C ABI of libultra_hip.so, the MI355X (gfx950) implementation of uLTRA's per-read
+ * alignment core (MAM finding + MAM chaining).
+ *
+ * The reference has no FFI for this path (it is pure Python calling the edlib wheel), so each
+ * entry point below cites the reference call site(s) whose arithmetic it replaces.  Citations are
+ * relative to /root/reference/.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every input and output buffer;
+ *   - all functions return 0 (ULTRA_OK) or a negative ULTRA_E_* code; ultra_last_error(ctx) gives
+ *     the text; nothing throws, nothing calls exit();
+ *   - sequences are compared byte-exact and case-sensitive ('N' is an ordinary symbol), as the
+ *     reference does (uLTRA:43, modules/create_augmented_gene.py:556);
+ *   - a ctx is bound to one GPU and is not thread-safe; different ctxs are independent;
+ *   - calls are synchronous on return unless the name says _stage/_run/_fetch.
+ */
+#ifndef ULTRA_HIP_H
+#define ULTRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULTRA_OK 0
+#define ULTRA_E_ARG (-1)         /* bad argument (null pointer, negative length, offsets out of range) */
+#define ULTRA_E_HIP (-2)         /* a HIP runtime call failed */
+#define ULTRA_E_CAPACITY (-3)    /* a caller-sized output is too small; the needed size is reported */
+#define ULTRA_E_UNSUPPORTED (-4) /* input outside the supported envelope (alphabet > 16 symbols, query > 32768) */
+#define ULTRA_E_NODEVICE (-5)    /* no usable gfx950 device */
+#define ULTRA_E_STATE (-6)       /* _run/_fetch called without a staged batch */
+
+typedef struct ultra_ctx ultra_ctx;
+
+/* Hard-coded constants of the reference's hot path, made explicit (defaults = reference values). */
+typedef struct ultra_cfg {
+    int32_t chain_switch_n;   /* > this many MAMs -> n log n solver   (classify_read_with_mams.py:561)  = 200 */
+    int32_t overlap_small;    /* overlap threshold of the quadratic solver (classify_read_with_mams.py:575) = 20 */
+    int32_t overlap_large;    /* overlap threshold of the n log n solver   (classify_read_with_mams.py:563) = 5 */
+    int32_t loc_slots;        /* end positions kept per pair in the first pass before the exact re-run = 8 */
+} ultra_cfg;
+
+void ultra_cfg_default(ultra_cfg *cfg);
+
+/* Library / device management (no reference counterpart: the reference has no device). */
+int ultra_ctx_create(int device, const ultra_cfg *cfg, ultra_ctx **out);
+void ultra_ctx_destroy(ultra_ctx *ctx);
+const char *ultra_last_error(const ultra_ctx *ctx);
+int ultra_device_count(void);
+/* name/CU count/clock of the ctx's device, for bench reports */
+int ultra_device_info(const ultra_ctx *ctx, char *name, int name_cap, int *n_cu, int *clock_khz);
+
+/*
+ * Batched semi-global ("HW", infix) Myers bit-vector search with locations and first-location path
+ * statistics.  Replaces, for a whole batch of (query, target) pairs,
+ *     edlib.align(query, target, task="path", mode="HW", k=k)
+ * as called at modules/classify_read_with_mams.py:99 (from :312 segment-in-read, :353 exact small
+ * segment, :377 read-in-segment) and consumed by edlib_alignment (:98-119) / cigar_to_accuracy (:71-94).
+ *
+ * arena[arena_len]       all sequences of the batch, raw bytes
+ * pair p                 query = arena[q_off[p] .. +q_len[p]), target = arena[t_off[p] .. +t_len[p]),
+ *                        k[p] = maximum distance (k < 0: unbounded)
+ * out ed[p]              best distance, or -1 when it exceeds k[p]  (edlib 'editDistance')
+ * out n_loc[p]           number of end positions attaining it
+ * out loc_off[n_pairs+1] CSR offsets into loc_start/loc_end (filled by the library)
+ * out loc_start/loc_end  inclusive 0-based target coordinates, ascending in end; start = smallest
+ *                        start whose global alignment to the query costs ed  (edlib 'locations')
+ * out first_ins[p]       number of inserted query bases ('I' columns) on the traceback path of the
+ *                        FIRST location (tie rule: up, then left, then diagonal). With
+ *                        L = end-start+1: accuracy = (L - ed + I) / (L + I)   (cigar_to_accuracy)
+ * loc_cap                capacity of loc_start/loc_end in entries. If too small the call returns
+ *                        ULTRA_E_CAPACITY and *loc_need holds the required number of entries.
+ * ops/ops_off            optional (may be NULL): per-pair edit script of the first location, written
+ *                        BACKWARDS (last column first) into ops[ops_off[p] .. ops_off[p+1]) as codes
+ *                        0 '=', 1 'I', 2 'D', 3 'X'; out n_ops[p] = number of codes written.
+ */
+int ultra_myers_hw_batch(ultra_ctx *ctx,
+                         const uint8_t *arena, size_t arena_len,
+                         int32_t n_pairs,
+                         const int64_t *q_off, const int32_t *q_len,
+                         const int64_t *t_off, const int32_t *t_len,
+                         const int32_t *k,
+                         int32_t *ed, int32_t *n_loc, int64_t *loc_off,
+                         int32_t *loc_start, int32_t *loc_end, int64_t loc_cap, int64_t *loc_need,
+                         int32_t *first_ins,
+                         uint8_t *ops, const int64_t *ops_off, int32_t *n_ops);
+
+/* The same work split in three so that a benchmark can time the device part alone with inputs
+ * resident in HBM: _stage copies and prepares (host -> device), _run launches every kernel of the
+ * batch and waits, _fetch copies results back (same output contract as above, without the
+ * optional edit scripts). */
+int ultra_myers_stage(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
+                      const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
+                      const int32_t *k);
+int ultra_myers_run(ultra_ctx *ctx);
+int ultra_myers_fetch(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_off,
+                      int32_t *loc_start, int32_t *loc_end, int64_t loc_cap, int64_t *loc_need,
+                      int32_t *first_ins);
+/* Forward-pass cell count (sum of q_len*t_len) and device milliseconds of the last _run, split by
+ * stage: [0] forward (distance + end positions), [1] reverse (start positions), [2] traceback,
+ * [3] everything (first launch to last completion).  Measured with HIP events on the ctx stream. */
+int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[4]);
+
+/*
+ * Batched MAM colinear chaining.  Replaces
+ *     colinear_solver.read_coverage_mam_score(mams, overlap_threshold=20)   (modules/colinear_solver.py:276-389)
+ *     colinear_solver.n_logn_read_coverage_mams(mams, overlap_threshold=5)  (modules/colinear_solver.py:394-493,
+ *         with modules/range_query_max_search_tree.py:19-157)
+ * and the solver switch at modules/classify_read_with_mams.py:560-575.
+ *
+ * Instances are given in CSR form: instance i owns MAMs inst_off[i] .. inst_off[i+1]), already
+ * sorted by y (stable), index j = position inside the instance.
+ * solver: 0 = pick by cfg.chain_switch_n (reference behaviour), 1 = force quadratic, 2 = force n log n.
+ * out chain_idx   caller-sized like the inputs; instance i's chain (ascending j) is written to
+ *                 chain_idx[inst_off[i] .. inst_off[i] + chain_len[i])
+ * out value[i]    optimal objective, FP64, bit-identical to the reference's arithmetic; -1 for an empty instance
+ * overlap thresholds < 0 select the cfg defaults.
+ */
+int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
+                           const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
+                           const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
+                           int32_t *chain_idx, int32_t *chain_len, double *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTRA_HIP_H */

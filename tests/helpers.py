@@ -1,0 +1,75 @@
+"""Shared generators for the parity tests (seeded, no reference code involved)."""
+import numpy as np
+
+
+def mutate(rng, s, rate):
+    out = []
+    for ch in s:
+        r = rng.rand()
+        if r < rate * 0.5:
+            continue
+        if r < rate * 0.8:
+            out.append("ACGT"[rng.randint(0, 4)])
+        elif r < rate:
+            out.append(ch)
+            out.append("ACGT"[rng.randint(0, 4)])
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def rand_seq(rng, n, alpha="ACGT"):
+    return "".join(alpha[i] for i in rng.randint(0, len(alpha), size=n))
+
+
+def make_pairs(rng, n_pairs, qlen_range, tlen_range, planted=0.5, rates=(0.0, 0.02, 0.07, 0.15, 0.3),
+               alpha="ACGT", kmode="ref"):
+    """Returns (arena uint8, q_off, q_len, t_off, t_len, k) with half the queries planted in the target."""
+    chunks, size = [], 0
+    q_off, q_len, t_off, t_len, ks = [], [], [], [], []
+    for _ in range(n_pairs):
+        n = int(rng.randint(tlen_range[0], tlen_range[1] + 1))
+        m = int(rng.randint(qlen_range[0], qlen_range[1] + 1))
+        t = rand_seq(rng, n, alpha)
+        if rng.rand() < planted and n > m:
+            a = int(rng.randint(0, n - m + 1))
+            q = mutate(rng, t[a:a + m], rates[int(rng.randint(0, len(rates)))]) or "A"
+        else:
+            q = rand_seq(rng, m, alpha)
+        if kmode == "ref":
+            k = int(0.4 * min(len(q), n))
+        elif kmode == "zero":
+            k = 0
+        elif kmode == "mixed":
+            k = [int(0.4 * min(len(q), n)), 0, len(q), -1, 3][int(rng.randint(0, 5))]
+        else:
+            k = int(kmode)
+        for s, offs, lens in ((q, q_off, q_len), (t, t_off, t_len)):
+            offs.append(size); lens.append(len(s))
+            chunks.append(s.encode()); size += len(s)
+        ks.append(k)
+    arena = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+    return arena, np.array(q_off, np.int64), np.array(q_len, np.int32), np.array(t_off, np.int64), \
+        np.array(t_len, np.int32), np.array(ks, np.int32)
+
+
+def make_mams(rng, n, readlen, ties):
+    """Random MAM instance sorted by y: arrays x, y, c, d, val."""
+    rows = []
+    for _ in range(n):
+        if ties:
+            L = int(rng.choice([10, 20, 30]))
+            c = int(rng.choice(np.arange(0, max(1, readlen - L), 5)))
+            x = int(rng.choice(np.arange(0, 5000, 50)))
+            y = x + L
+            val = float(L) * float(rng.choice([1.0, 0.9]))
+        else:
+            L = int(rng.randint(5, 61))
+            c = int(rng.randint(0, max(1, readlen - L)))
+            x = int(rng.randint(0, 5001))
+            y = x + L + int(rng.randint(0, 4))
+            val = float(L) if rng.rand() < 0.3 else L * float(rng.choice([0.7, 0.8, 0.9, 1.0, rng.rand()]))
+        rows.append((x, y, c, c + L - 1, val))
+    rows.sort(key=lambda r: r[1])
+    a = np.array([r[:4] for r in rows], np.int32).reshape(-1, 4)
+    return a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy(), a[:, 3].copy(), np.array([r[4] for r in rows], np.float64)

@@ -1,0 +1,107 @@
+"""GPU parity: libultra_hip Myers batch (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, pairs, want_ops=False):
+    from oracle import cport
+    arena, q_off, q_len, t_off, t_len, k = pairs
+    got = ctx.myers_hw_batch(arena, q_off, q_len, t_off, t_len, k, want_ops=want_ops)
+    cap = np.maximum(got["n_loc"].astype(np.int64), 1) + 1
+    loc_off = np.zeros(len(k) + 1, np.int64); np.cumsum(cap, out=loc_off[1:])
+    ed, nl, st, en, fi, ovf = cport.hw_batch(arena, q_off, q_len, t_off, t_len, k, loc_off)
+    assert ovf == 0
+    assert np.array_equal(got["ed"], ed)
+    assert np.array_equal(got["n_loc"], nl)
+    assert np.array_equal(got["first_ins"], fi)
+    for p in range(len(k)):
+        a, b = int(got["loc_off"][p]), int(got["loc_off"][p + 1])
+        o = int(loc_off[p])
+        assert np.array_equal(got["loc_end"][a:b], en[o:o + nl[p]]), p
+        assert np.array_equal(got["loc_start"][a:b], st[o:o + nl[p]]), p
+    if want_ops:
+        for p in range(len(k)):
+            if ed[p] < 0:
+                continue
+            q = bytes(arena[q_off[p]:q_off[p] + q_len[p]]); t = bytes(arena[t_off[p]:t_off[p] + t_len[p]])
+            ref = cport.hw_align(q, t, int(k[p]))
+            n = int(got["n_ops"][p])
+            ops = got["ops"][int(got["ops_off"][p]):int(got["ops_off"][p]) + n][::-1]
+            assert cport.ops_to_cigar(ops.tolist()) == ref["cigar"], p
+    return got
+
+
+@pytest.mark.parametrize("qr,tr,n", [((1, 64), (20, 400), 3000), ((60, 140), (100, 1200), 3000),
+                                      ((120, 520), (300, 1500), 1500)])
+def test_lane_kernels_match_oracle(ctx, qr, tr, n):
+    rng = np.random.RandomState(hash((qr, tr)) % (2 ** 31))
+    _check(ctx, helpers.make_pairs(rng, n, qr, tr, kmode="mixed"))
+
+
+def test_group_kernels_match_oracle(ctx):
+    rng = np.random.RandomState(77)
+    _check(ctx, helpers.make_pairs(rng, 120, (513, 2100), (400, 2600), kmode="ref"))
+    _check(ctx, helpers.make_pairs(rng, 24, (2100, 9000), (1500, 9000), kmode="ref", rates=(0.02, 0.1)))
+
+
+def test_small_exact_and_many_locations(ctx):
+    # 5-8 bp exact segments (k = 0) and low-complexity targets: many end positions, slot overflow path
+    rng = np.random.RandomState(5)
+    _check(ctx, helpers.make_pairs(rng, 2000, (5, 8), (50, 1000), kmode="zero", alpha="AC"))
+    _check(ctx, helpers.make_pairs(rng, 500, (5, 30), (200, 1000), kmode="ref", alpha="A"))
+    _check(ctx, helpers.make_pairs(rng, 500, (9, 40), (200, 800), kmode="ref", alpha="AC"))
+
+
+def test_alphabet_is_byte_exact(ctx):
+    rng = np.random.RandomState(6)
+    _check(ctx, helpers.make_pairs(rng, 800, (9, 200), (100, 600), kmode="ref", alpha="ACGTNacgtn"))
+
+
+def test_edit_scripts(ctx):
+    rng = np.random.RandomState(8)
+    _check(ctx, helpers.make_pairs(rng, 600, (9, 300), (100, 700), kmode="ref", planted=0.8), want_ops=True)
+    _check(ctx, helpers.make_pairs(rng, 30, (600, 1500), (800, 2000), kmode="ref", planted=0.9), want_ops=True)
+
+
+def test_query_longer_than_target_and_contained_reads(ctx):
+    rng = np.random.RandomState(9)
+    # read-in-segment shape: query (read) about as long as or longer than the target (segment)
+    _check(ctx, helpers.make_pairs(rng, 300, (200, 600), (150, 700), kmode="ref", planted=0.0))
+
+
+def test_empty_batch_and_bad_arguments(ctx):
+    from ultra_amd import lib
+    r = ctx.myers_hw_batch(np.zeros(4, np.uint8), [], [], [], [], [])
+    assert len(r["ed"]) == 0 and r["loc_off"][0] == 0
+    with pytest.raises(lib.UltraError):
+        ctx.myers_hw_batch(np.zeros(4, np.uint8), [0], [3], [2], [9], [1])      # target outside the arena
+    with pytest.raises(lib.UltraError):
+        ctx.myers_hw_batch(np.zeros(4, np.uint8), [0], [0], [0], [4], [1])      # empty query
+    with pytest.raises(lib.UltraError):
+        ctx.myers_hw_batch(np.arange(64, dtype=np.uint8), [0], [30], [30], [30], [5])  # > 16 distinct symbols
+
+
+def test_round_trip_property_at_scale(ctx):
+    """Size-independent property at a bench-like size: a planted query is found at distance <= its
+    simulated error count, and every reported (start, end) re-aligns globally to exactly ed."""
+    from oracle import cport
+    rng = np.random.RandomState(10)
+    pairs = helpers.make_pairs(rng, 20000, (9, 300), (800, 1200), kmode="ref")
+    arena, q_off, q_len, t_off, t_len, k = pairs
+    got = ctx.myers_hw_batch(arena, q_off, q_len, t_off, t_len, k)
+    hits = np.nonzero(got["ed"] >= 0)[0]
+    assert len(hits) > 5000
+    for p in hits[:: max(1, len(hits) // 400)]:
+        q = bytes(arena[q_off[p]:q_off[p] + q_len[p]]); t = bytes(arena[t_off[p]:t_off[p] + t_len[p]])
+        a, b = int(got["loc_off"][p]), int(got["loc_off"][p + 1])
+        assert b > a
+        for s, e in zip(got["loc_start"][a:b], got["loc_end"][a:b]):
+            sub = t[s:e + 1]
+            r = cport.hw_align(q, sub, len(q), want_path=False)
+            # global distance of q vs t[s..e] equals ed: HW on the exact window cannot do better,
+            # and the window achieves it only if both ends are used
+            assert r["editDistance"] <= got["ed"][p]

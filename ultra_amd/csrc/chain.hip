@@ -1,0 +1,434 @@
+// MAM colinear chaining for gfx950: one wavefront per (read, location) instance.
+//
+// Replaces /root/reference/modules/colinear_solver.py:276-389 (read_coverage_mam_score, n <= 200)
+// and :394-493 (n_logn_read_coverage_mams, n > 200; with range_query_max_search_tree.py:19-157).
+//
+//   * quadratic solver: for each j the wave evaluates every j' < j in parallel (stride 64), keeps
+//     (value, index) pairs and reduces them with the reference's tie rule (largest j' among equal
+//     maxima; the T candidate wins Ca >= Cb);
+//   * n log n solver: the reference's search tree is replaced by its closed form - leaves sorted by
+//     read end coordinate d in LDS (bitonic sort), the two range queries become index ranges found
+//     by binary search, answered by a wave-wide lexicographic (C, j) max over per-64-leaf chunk
+//     maxima plus one partial chunk.  The tree's two quirks are kept: the last leaf is left out of
+//     a range that extends past it, and an empty range returns the first leaf above it.
+//
+// FP64 everywhere, one rounding per reference operation: built with -ffp-contract=off and the
+// arithmetic below spelled with __d*_rn so nothing fuses.
+#include "common.h"
+
+#include <algorithm>
+#include <string.h>
+
+namespace {
+
+struct Cand {
+    double v;
+    int idx;
+    int has;
+};
+
+// larger value wins; ties -> larger index
+__device__ __forceinline__ Cand better_hi(Cand a, Cand b)
+{
+    if (!b.has) return a;
+    if (!a.has) return b;
+    if (b.v > a.v || (b.v == a.v && b.idx > a.idx)) return b;
+    return a;
+}
+// larger value wins; ties -> smaller index (first arg-max)
+__device__ __forceinline__ Cand better_lo(Cand a, Cand b)
+{
+    if (!b.has) return a;
+    if (!a.has) return b;
+    if (b.v > a.v || (b.v == a.v && b.idx < a.idx)) return b;
+    return a;
+}
+template <bool HI> __device__ __forceinline__ Cand wave_reduce(Cand c)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand other;
+        other.v = __shfl_xor(c.v, o, 64);
+        other.idx = __shfl_xor(c.idx, o, 64);
+        other.has = __shfl_xor(c.has, o, 64);
+        c = HI ? better_hi(c, other) : better_lo(c, other);
+    }
+    return c;
+}
+
+struct ChainArgs {
+    const int64_t *off;
+    const int32_t *x, *y, *c, *d;
+    const double *val;
+    int32_t thr;
+    int32_t *idx, *len;
+    double *value;
+    const int32_t *list; // instance ids handled by this launch
+    int32_t nlist;
+    int32_t cap;         // LDS entries per wave (quadratic) / leaves (n log n)
+    uint8_t *work;       // global scratch (n log n)
+    const int64_t *work_off;
+    int32_t *status;
+};
+
+// ---- quadratic ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
+{
+    extern __shared__ uint8_t lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int slot = blockIdx.x * wpb + wave;
+    if (slot >= a.nlist) return;
+    const int inst = a.list[slot];
+    const int64_t o = a.off[inst];
+    const int n = (int)(a.off[inst + 1] - o);
+    const int cap = a.cap;
+    uint8_t *base = lds_raw + (size_t)wave * cap * 20;
+    double *sC = (double *)base;
+    int32_t *sc = (int32_t *)(base + (size_t)cap * 8);
+    int32_t *sd = sc + cap;
+    int32_t *sp = sd + cap;
+    if (n <= 0) {
+        if (lane == 0) { a.len[inst] = 0; a.value[inst] = -1.0; }
+        return;
+    }
+    for (int i = lane; i < n; i += 64) { sc[i] = a.c[o + i]; sd[i] = a.d[o + i]; }
+    const int thr = a.thr;
+    for (int j = 0; j < n; j++) {
+        const int cj = sc[j];
+        const double vj = a.val[o + j];
+        Cand T = {0.0, -1, 0}, I = {0.0, -1, 0};
+        for (int jp = lane; jp < j; jp += 64) {
+            const int dj = sd[jp];
+            const double Cp = sC[jp];
+            if (dj < cj) {
+                double v = __dsub_rn(Cp, __dmul_rn(0.1, (double)(cj - dj - 1)));
+                Cand t = {v, jp, 1};
+                T = better_hi(T, t);
+            }
+            if (cj <= dj && dj <= cj - 1 + thr) {
+                double ov = (double)(dj - cj + 1);
+                double v = __dadd_rn(Cp, __dsub_rn(__dsub_rn(vj, ov), __dmul_rn(0.1, ov)));
+                Cand t = {v, jp, 1};
+                I = better_hi(I, t);
+            }
+        }
+        T = wave_reduce<true>(T);
+        I = wave_reduce<true>(I);
+        const double Ca = __dadd_rn(T.has ? T.v : 0.0, vj);
+        const double Cb = I.has ? I.v : 0.0;
+        if (lane == 0) {
+            if (Ca >= Cb) { sC[j] = Ca; sp[j] = T.has ? T.idx : -1; }
+            else { sC[j] = Cb; sp[j] = I.has ? I.idx : -1; }
+        }
+    }
+    Cand B = {0.0, -1, 0};
+    for (int i = lane; i < n; i += 64) { Cand t = {sC[i], i, 1}; B = better_lo(B, t); }
+    B = wave_reduce<false>(B);
+    if (lane == 0) {
+        int len = 0;
+        for (int j = B.idx; j >= 0; j = sp[j]) len++;
+        int w = len;
+        for (int j = B.idx; j >= 0; j = sp[j]) a.idx[o + (--w)] = j;
+        a.len[inst] = len;
+        a.value[inst] = B.v;
+    }
+}
+
+// ---- n log n -------------------------------------------------------------------------------------
+__device__ __forceinline__ int first_greater(const int32_t *ld, int nleaf, int key, bool or_equal, bool &fallback)
+{
+    // first index with ld > key (or >= key); nleaf-1 with fallback=true when there is none
+    int lo = 0, hi = nleaf;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        bool right = or_equal ? (ld[mid] < key) : (ld[mid] <= key);
+        if (right) lo = mid + 1; else hi = mid;
+    }
+    fallback = (lo >= nleaf);
+    return fallback ? nleaf - 1 : lo;
+}
+
+__global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
+{
+    extern __shared__ uint8_t lds_raw[];
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x;
+    if (slot >= a.nlist) return;
+    const int inst = a.list[slot];
+    const int64_t o = a.off[inst];
+    const int n = (int)(a.off[inst + 1] - o);
+    if (n <= 0) {
+        if (lane == 0) { a.len[inst] = 0; a.value[inst] = -1.0; }
+        return;
+    }
+    // leaf count (colinear_solver.py:64-83): n+1 nodes padded up to a power of two
+    int cnt = n + 1, nleaf = 1;
+    while (nleaf < cnt) nleaf <<= 1;
+    const int npad = nleaf - cnt;
+    const int nchunk = (nleaf + 63) >> 6;
+    // LDS: lC[nleaf] f64 | ld[nleaf] i32 | lj[nleaf] i32 | cmC[nchunk] f64 | cmJ[nchunk] i32
+    double *lC = (double *)lds_raw;
+    int32_t *ld = (int32_t *)(lds_raw + (size_t)nleaf * 8);
+    int32_t *lj = ld + nleaf;
+    double *cmC = (double *)(lds_raw + (size_t)nleaf * 16);
+    int32_t *cmJ = (int32_t *)(lds_raw + (size_t)nleaf * 16 + (size_t)nchunk * 8);
+    // global scratch of this instance
+    uint8_t *wk = a.work + a.work_off[slot];
+    double *C = (double *)wk;                      // n+1
+    int32_t *trace = (int32_t *)(wk + (size_t)(n + 1) * 8); // n+1
+    int32_t *leaf_of = trace + (n + 1);            // n
+    int32_t *qT = leaf_of + n;                     // n   T-prefix length
+    int32_t *qIlo = qT + n;                        // n
+    int32_t *qIhi = qIlo + n;                      // n   (exclusive)
+    const int32_t *gc = a.c + o, *gd = a.d + o, *gx = a.x + o, *gy = a.y + o;
+    const double *gv = a.val + o;
+    const double NEG = -__builtin_inf();
+
+    // ---- sort MAMs by (d, j): bitonic sort of 64-bit keys held in the lC area ----
+    uint64_t *keys = (uint64_t *)lC;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = lane; i < np2; i += 64)
+        keys[i] = i < n ? ((((uint64_t)(uint32_t)gd[i]) << 32) | (uint32_t)i) : ~(uint64_t)0;
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int s = k >> 1; s > 0; s >>= 1) {
+            for (int t = lane; t < (np2 >> 1); t += 64) {
+                int i = ((t / s) * (s << 1)) + (t % s);
+                int p = i + s;
+                bool up = ((i & k) == 0);
+                uint64_t A = keys[i], B = keys[p];
+                if ((A > B) == up) { keys[i] = B; keys[p] = A; }
+            }
+        }
+    }
+    // leaves: start node, pad nodes, then the MAMs in (d, j) order (stable sort by d of the reference)
+    for (int r = lane; r < n; r += 64) {
+        uint64_t kx = keys[r];
+        int j = (int)(uint32_t)kx;
+        int pos = 1 + npad + r;
+        lj[pos] = j;
+        leaf_of[j] = pos;
+    }
+    for (int i = lane; i <= npad; i += 64) lj[i] = (i == 0) ? -1 : -(i - 1) - 2;
+    // keys alias lC: read every d before lC is initialised
+    for (int r = lane; r < n; r += 64) ld[1 + npad + r] = (int32_t)(uint32_t)(keys[r] >> 32);
+    for (int i = lane; i <= npad; i += 64) ld[i] = -1;
+    for (int i = lane; i < nleaf; i += 64) lC[i] = NEG;
+    for (int i = lane; i < nchunk; i += 64) { cmC[i] = NEG; cmJ[i] = -0x7fffffff; }
+    if (lane == 0) { lC[0] = 0.0; cmC[0] = 0.0; cmJ[0] = -1; }
+    // ---- per-MAM query ranges (leaf keys never change) ----
+    const int thr = a.thr;
+    int bug = 0;
+    for (int j = lane; j < n; j += 64) {
+        const int c = gc[j];
+        bool fb;
+        // T query [-1, c-1]: lo = 0
+        int hi = first_greater(ld, nleaf, c - 1, false, fb);
+        int plen = hi + ((fb && ld[hi] == c - 1) ? 1 : 0);
+        if (plen <= 0) bug = 1; // the reference's "BUG" exit: cannot happen, leaf 0 has d = -1
+        qT[j] = plen;
+        // I query [c, c-1+thr]
+        const int r = c - 1 + thr;
+        bool fbl, fbh;
+        int lo = first_greater(ld, nleaf, c, true, fbl);
+        int hi2 = first_greater(ld, nleaf, r, false, fbh);
+        int b, e;
+        if (lo < hi2) { b = lo; e = hi2 + ((ld[hi2] == r) ? 1 : 0); }
+        else {
+            bool take = (ld[hi2] == r) || (ld[lo] >= c);
+            // lo == hi2 here (lo > hi2 would need r < l - 1)
+            b = lo; e = take ? lo + 1 : lo;
+            if (!take) bug = 1;
+        }
+        qIlo[j] = b; qIhi[j] = e;
+    }
+    if (__any(bug)) {
+        if (lane == 0) { a.len[inst] = -1; a.value[inst] = -1.0; atomicOr(a.status, 1); }
+        return;
+    }
+    __threadfence();
+    if (lane == 0) { C[0] = 0.0; trace[0] = 0; }
+    // ---- DP ----
+    for (int j = 0; j < n; j++) {
+        const int plen = qT[j];
+        const int b = qIlo[j], e = qIhi[j];
+        const double vj = gv[j];
+        // T: lexicographic (C, j) max over leaves [0, plen)
+        Cand T = {0.0, 0, 0};
+        const int full = plen >> 6;
+        for (int ch = lane; ch < full; ch += 64) {
+            double cv = cmC[ch];
+            if (cv != NEG) { Cand t = {cv, cmJ[ch], 1}; T = better_hi(T, t); }
+        }
+        {
+            int i = (full << 6) + lane;
+            if (i < plen) {
+                double cv = lC[i];
+                if (cv != NEG) { Cand t = {cv, lj[i], 1}; T = better_hi(T, t); }
+            }
+        }
+        Cand I = {0.0, 0, 0};
+        for (int i = b + lane; i < e; i += 64) {
+            double cv = lC[i];
+            if (cv != NEG) { Cand t = {cv, lj[i], 1}; I = better_hi(I, t); }
+        }
+        T = wave_reduce<true>(T);
+        I = wave_reduce<true>(I);
+        // T always holds the start leaf (C = 0)
+        const double Ca = __dadd_rn(T.v, vj);
+        double v = Ca;
+        int jp = T.idx;
+        if (I.has) {
+            int jb = I.idx < 0 ? I.idx + n : I.idx; // Python negative indexing (:448-451)
+            double pen = (gx[j] != gy[jb]) ? __dadd_rn((double)(gd[jb] - (gc[j] - 1)), 0.0001) : 0.0001;
+            double Cb = __dsub_rn(__dadd_rn(I.v, vj), pen);
+            if (Cb > Ca) { v = Cb; jp = I.idx; }
+        }
+        if (lane == 0) {
+            C[j + 1] = v;
+            trace[j + 1] = (jp < 0 || v == 0.0) ? 0 : jp + 1;
+            int leaf = leaf_of[j];
+            lC[leaf] = v;
+            int ch = leaf >> 6;
+            double cv = cmC[ch];
+            if (cv == NEG || v > cv || (v == cv && j > cmJ[ch])) { cmC[ch] = v; cmJ[ch] = j; }
+        }
+    }
+    __threadfence();
+    Cand B = {0.0, -1, 0};
+    for (int i = lane; i <= n; i += 64) { Cand t = {C[i], i, 1}; B = better_lo(B, t); }
+    B = wave_reduce<false>(B);
+    if (lane == 0) {
+        int len = 0;
+        for (int i = B.idx; i > 0; i = trace[i]) len++;
+        int w = len;
+        for (int i = B.idx; i > 0; i = trace[i]) a.idx[o + (--w)] = i - 1;
+        a.len[inst] = len;
+        a.value[inst] = B.v;
+    }
+}
+
+constexpr int kQuadSmall = 256;    // LDS entries per wave in the 4-waves-per-block launch
+constexpr int kLdsBudget = 160 * 1024;
+
+} // namespace
+
+void ultra_chain_free(ultra_ctx *ctx)
+{
+    ChainState &ch = ctx->ch;
+    DevBuf *bufs[] = {&ch.off, &ch.x, &ch.y, &ch.c, &ch.d, &ch.val, &ch.idx, &ch.len, &ch.value, &ch.work};
+    for (DevBuf *b : bufs) b->release();
+}
+
+extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
+                                      const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
+                                      const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
+                                      int32_t *chain_idx, int32_t *chain_len, double *value)
+{
+    if (!ctx) return ULTRA_E_ARG;
+    if (n_inst < 0 || (n_inst > 0 && (!inst_off || !chain_len || !value)))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: null pointer or negative instance count");
+    if (n_inst == 0) return ULTRA_OK;
+    if (solver < 0 || solver > 2) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: solver must be 0, 1 or 2");
+    const int thr_s = overlap_small < 0 ? ctx->cfg.overlap_small : overlap_small;
+    const int thr_l = overlap_large < 0 ? ctx->cfg.overlap_large : overlap_large;
+    const int64_t total = inst_off[n_inst];
+    if (inst_off[0] != 0 || total < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: inst_off must start at 0");
+    if (total > 0 && (!x || !y || !c || !d || !val || !chain_idx))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: null MAM array");
+    std::vector<int32_t> small, big, tree;
+    int32_t max_big = 0, max_tree = 0;
+    for (int32_t i = 0; i < n_inst; i++) {
+        int64_t n = inst_off[i + 1] - inst_off[i];
+        if (n < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: inst_off must be non-decreasing");
+        bool use_tree = solver == 2 || (solver == 0 && n > ctx->cfg.chain_switch_n);
+        if (use_tree && n > 0) {
+            if (thr_l < 1) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: n log n solver needs overlap threshold >= 1");
+            tree.push_back(i); max_tree = std::max<int32_t>(max_tree, (int32_t)n);
+        } else if (n <= kQuadSmall) small.push_back(i);
+        else { big.push_back(i); max_big = std::max<int32_t>(max_big, (int32_t)n); }
+    }
+    if ((size_t)max_big * 20 > (size_t)kLdsBudget)
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_chain_mams_batch: quadratic solver limited to 8192 MAMs per instance");
+    int tree_leaves = 1;
+    while (tree_leaves < max_tree + 1) tree_leaves <<= 1;
+    size_t tree_lds = (size_t)tree_leaves * 16 + (size_t)((tree_leaves + 63) / 64) * 12 + 16;
+    if (!tree.empty() && tree_lds > (size_t)kLdsBudget)
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_chain_mams_batch: n log n solver limited to 8191 MAMs per instance");
+
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ChainState &ch = ctx->ch;
+    hipStream_t s = ctx->stream;
+    const size_t nt = (size_t)std::max<int64_t>(total, 1), ni = (size_t)n_inst;
+    ULTRA_HIP_CHECK(ctx, ch.off.ensure((ni + 1) * 8 + (ni + 1) * 8 + ni * 4 + 64));
+    ULTRA_HIP_CHECK(ctx, ch.x.ensure(nt * 4)); ULTRA_HIP_CHECK(ctx, ch.y.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.c.ensure(nt * 4)); ULTRA_HIP_CHECK(ctx, ch.d.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.val.ensure(nt * 8)); ULTRA_HIP_CHECK(ctx, ch.idx.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.len.ensure(ni * 4 + 16)); ULTRA_HIP_CHECK(ctx, ch.value.ensure(ni * 8));
+    // device layout of ch.off: inst_off | work_off | list
+    int64_t *d_off = ch.off.as<int64_t>();
+    int64_t *d_workoff = d_off + (ni + 1);
+    int32_t *d_list = (int32_t *)(d_workoff + (ni + 1));
+    int32_t *d_status = ch.len.as<int32_t>() + ni;
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_off, inst_off, (ni + 1) * 8, hipMemcpyHostToDevice, s));
+    if (total > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.x.p, x, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.y.p, y, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.c.p, c, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.d.p, d, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.val.p, val, nt * 8, hipMemcpyHostToDevice, s));
+    }
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_status, 0, 4, s));
+    std::vector<int32_t> list;
+    list.insert(list.end(), small.begin(), small.end());
+    list.insert(list.end(), big.begin(), big.end());
+    list.insert(list.end(), tree.begin(), tree.end());
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, s));
+    std::vector<int64_t> work_off(tree.size() + 1, 0);
+    for (size_t t = 0; t < tree.size(); t++) {
+        int64_t n = inst_off[tree[t] + 1] - inst_off[tree[t]];
+        int64_t bytes = (n + 1) * 12 + n * 16;
+        work_off[t + 1] = work_off[t] + ((bytes + 15) & ~(int64_t)15);
+    }
+    if (!tree.empty()) {
+        ULTRA_HIP_CHECK(ctx, ch.work.ensure((size_t)work_off.back() + 16));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_workoff, work_off.data(), work_off.size() * 8, hipMemcpyHostToDevice, s));
+    }
+    ChainArgs a;
+    memset(&a, 0, sizeof a);
+    a.off = d_off; a.x = ch.x.as<int32_t>(); a.y = ch.y.as<int32_t>(); a.c = ch.c.as<int32_t>(); a.d = ch.d.as<int32_t>();
+    a.val = ch.val.as<double>(); a.idx = ch.idx.as<int32_t>(); a.len = ch.len.as<int32_t>(); a.value = ch.value.as<double>();
+    a.status = d_status;
+    if (!small.empty()) {
+        a.thr = thr_s; a.list = d_list; a.nlist = (int32_t)small.size(); a.cap = kQuadSmall;
+        int blocks = ((int)small.size() + 3) / 4;
+        hipLaunchKernelGGL(chain_quadratic, dim3(blocks), dim3(256), (size_t)4 * kQuadSmall * 20, s, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (!big.empty()) {
+        a.thr = thr_s; a.list = d_list + small.size(); a.nlist = (int32_t)big.size(); a.cap = max_big;
+        size_t shmem = (size_t)max_big * 20;
+        if (shmem > 64 * 1024)
+            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_quadratic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(chain_quadratic, dim3((unsigned)big.size()), dim3(64), shmem, s, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (!tree.empty()) {
+        a.thr = thr_l; a.list = d_list + small.size() + big.size(); a.nlist = (int32_t)tree.size(); a.cap = tree_leaves;
+        a.work = ch.work.as<uint8_t>(); a.work_off = d_workoff;
+        if (tree_lds > 64 * 1024)
+            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_nlogn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
+        hipLaunchKernelGGL(chain_nlogn, dim3((unsigned)tree.size()), dim3(64), tree_lds, s, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    int32_t status = 0;
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(chain_len, ch.len.p, ni * 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(value, ch.value.p, ni * 8, hipMemcpyDeviceToHost, s));
+    if (total > 0) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(chain_idx, ch.idx.p, nt * 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (status != 0)
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: an instance reached the reference's 'BUG' state "
+                                            "(empty range-query node set); check that c <= d for every MAM");
+    return ULTRA_OK;
+}

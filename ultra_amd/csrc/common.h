@@ -1,0 +1,95 @@
+// Shared host-side plumbing for libultra_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ultra_hip.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+// One size class of the Myers kernels: G lanes per pair, W 64-row blocks per lane.
+struct MyersClass {
+    int G, W;           // rows covered = 64*G*W
+    int64_t pb, pe;     // pair range (sorted order)
+    int32_t max_t;      // longest target in the class
+    int64_t lb, le;     // location (CSR) range, known after the forward pass
+    int64_t hb, he;     // hit (ed >= 0) range
+};
+
+struct MyersState {
+    bool staged = false, ran = false;
+    int32_t n_pairs = 0;
+    int64_t N = 0;      // arena length
+    int S = 0;          // alphabet size of the batch (distinct bytes)
+    std::vector<int32_t> perm;      // sorted position -> caller's pair index
+    std::vector<MyersClass> classes;
+    std::vector<int64_t> h_qoff, h_toff;
+    std::vector<int32_t> h_qlen, h_tlen, h_k;
+    double cells = 0;
+    float ms[4] = {0, 0, 0, 0};
+    int64_t total_loc = 0, total_hit = 0;
+    DevBuf seq, rseq, qoff, qlen, toff, tlen, k, ed, nloc, slots, packed, scanned, blocksum, locoff, hitoff,
+        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+struct ChainState {
+    DevBuf off, x, y, c, d, val, idx, len, value, work;
+};
+
+struct ultra_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ultra_cfg cfg;
+    std::string err;
+    hipDeviceProp_t prop;
+    MyersState my;
+    ChainState ch;
+};
+
+#define ULTRA_HIP_CHECK(ctx, call)                                                                      \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            char b__[512];                                                                              \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                     __LINE__);                                                                         \
+            (ctx)->err = b__;                                                                           \
+            return ULTRA_E_HIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+static inline int ultra_fail(ultra_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
+                           const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
+                           const int32_t *k);
+int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops);
+void ultra_myers_free(ultra_ctx *ctx);
+void ultra_chain_free(ultra_ctx *ctx);

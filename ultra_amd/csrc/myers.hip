@@ -1,0 +1,795 @@
+// Myers / Hyyro bit-vector semi-global search for gfx950 (wave64), hand-written for CDNA4.
+//
+// Replaces the arithmetic behind edlib.align(query, target, task="path", mode="HW", k) as the
+// reference calls it at /root/reference/modules/classify_read_with_mams.py:99 (:312, :353, :377).
+//
+// Layout choices (not a translation of edlib):
+//   * the query is padded at the TOP of its first 64-row word, so the last query row is always
+//     bit 63 of the last word and the bottom-row score is the running sum of the last word's
+//     horizontal carry - no per-column bit extraction, no "last W columns" epilogue;
+//   * lane-per-pair kernels (W = 1..8 words in registers) for queries up to 512 bases: 64 independent
+//     pairs per wavefront, zero cross-lane traffic, Peq[sym][word][lane] in LDS (conflict-free
+//     ds_read_b64: the bank depends on the lane only);
+//   * lane-group kernels for longer queries: G lanes per pair, W words per lane, anti-diagonal
+//     (skewed) schedule, the horizontal carry moves one lane per step;
+//   * three passes: forward HW (distance + end columns), reverse anchored pass per end column
+//     (start = smallest start), NW pass that stores every column followed by a traceback of the
+//     first location (insertion count / edit script).
+#include "common.h"
+
+#include <algorithm>
+#include <string.h>
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_FWD_EXACT = 1, MODE_REV = 2, MODE_NW = 3 };
+
+struct MyArgs {
+    const uint8_t *seq, *rseq;
+    int64_t N;
+    int S;
+    const int64_t *q_off; const int32_t *q_len; const int64_t *t_off; const int32_t *t_len; const int32_t *k;
+    int32_t *ed; int32_t *nloc; int32_t *slots; int slot_cap;
+    const int64_t *loc_off; int32_t *loc_end; int32_t *loc_start; const int32_t *loc_pair;
+    const int32_t *hit_pairs; int32_t *first_ins;
+    uint64_t *trP, *trM; int32_t *trS; int64_t region; // trace scratch, entries per wave (lane kernels) / per pair slot (group kernels)
+    int32_t Lmax;
+    uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
+    int64_t begin, end;
+};
+
+struct Item {
+    const uint8_t *q, *t;
+    int32_t m, n, k, pair, best;
+    bool valid;
+};
+
+template <int MODE> __device__ __forceinline__ Item setup_item(const MyArgs &a, int64_t item)
+{
+    Item it;
+    it.valid = item < a.end;
+    it.q = a.seq; it.t = a.seq; it.m = 1; it.n = 0; it.k = 0; it.pair = 0; it.best = 0;
+    if (!it.valid) return it;
+    if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
+        int32_t p = (int32_t)item;
+        it.pair = p;
+        it.m = a.q_len[p]; it.n = a.t_len[p];
+        it.q = a.seq + a.q_off[p]; it.t = a.seq + a.t_off[p];
+        int32_t k = a.k[p];
+        it.k = (k < 0 || k > it.m) ? it.m : k;
+        if (MODE == MODE_FWD_EXACT) it.valid = a.nloc[p] > a.slot_cap;
+    } else if (MODE == MODE_REV) {
+        int32_t p = a.loc_pair[item];
+        int32_t e = a.loc_end[item];
+        it.pair = p;
+        it.m = a.q_len[p];
+        it.best = a.ed[p];
+        int32_t lim = it.m + it.best;
+        if (lim > e + 1) lim = e + 1;
+        it.n = lim;
+        it.k = it.best;
+        it.q = a.rseq + (a.N - a.q_off[p] - it.m);
+        it.t = a.rseq + (a.N - a.t_off[p] - (int64_t)(e + 1));
+    } else {
+        int32_t p = a.hit_pairs[item];
+        int64_t lo = a.loc_off[p];
+        int32_t s = a.loc_start[lo], e = a.loc_end[lo];
+        it.pair = p;
+        it.m = a.q_len[p];
+        it.best = a.ed[p];
+        it.n = e - s + 1;
+        it.k = it.best;
+        it.q = a.seq + a.q_off[p];
+        it.t = a.seq + a.t_off[p] + s;
+    }
+    return it;
+}
+
+__device__ __forceinline__ uint64_t load8(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8); // arena is padded: reading a few bytes past a slice is safe
+    return v;
+}
+
+// One 64-row word, one column (Hyyro 2003 formulation of Myers 1999).  hp/hm = horizontal
+// carry into the word's top row (+1 / -1), updated to the carry out of its bottom row.
+__device__ __forceinline__ void word_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t &hp, uint32_t &hm)
+{
+    uint64_t Xv = Eq | Mv;
+    Eq |= (uint64_t)hm;
+    uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    uint64_t u = Xh | Pv;
+    uint64_t Ph = (u & Mv) | ~u; // = Mv | ~(Xh | Pv)
+    uint64_t Mh = Pv & Xh;
+    uint32_t hpo = (uint32_t)(Ph >> 63), hmo = (uint32_t)(Mh >> 63);
+    Ph = (Ph << 1) | (uint64_t)hp;
+    Mh = (Mh << 1) | (uint64_t)hm;
+    uint64_t w = Xv | Ph;
+    Pv = (w & Mh) | ~w; // = Mh | ~(Xv | Ph)
+    Mv = Ph & Xv;
+    hp = hpo; hm = hmo;
+}
+
+__device__ __forceinline__ uint64_t pad_mask(int pad, int blk) // bits of word blk whose global row index < pad
+{
+    int r = pad - 64 * blk;
+    if (r <= 0) return 0;
+    if (r >= 64) return ~(uint64_t)0;
+    return (((uint64_t)1) << r) - 1;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Traceback helpers: column-major store of (Pv, Mv, bottom score) per word; stride = distance between
+// consecutive words of one pair, colstride = distance between columns.
+struct TraceView {
+    const uint64_t *P, *M; const int32_t *S;
+    int64_t stride, colstride;
+    int pad;
+    __device__ __forceinline__ int cell(int ip, int c) const
+    {
+        int64_t o = (int64_t)c * colstride + (int64_t)(ip >> 6) * stride;
+        uint64_t p = P[o], m = M[o];
+        int pos = ip & 63;
+        p = (p >> pos) >> 1; m = (m >> pos) >> 1;
+        return S[o] - (__popcll(p) - __popcll(m));
+    }
+    // value at padded row ip (-1 = above everything), column c (-1 = left boundary)
+    __device__ __forceinline__ int D(int ip, int c) const
+    {
+        if (c < 0) { int v = ip - pad + 1; return v > 0 ? v : 0; }
+        if (ip < 0) return c + 1;
+        return cell(ip, c);
+    }
+};
+
+// Walks the first location's path from the bottom-right cell; tie rule: up (I), left (D), diagonal.
+__device__ __forceinline__ void traceback(const TraceView &tv, int rows, int L, int best,
+                                          uint8_t *ops, int ops_cap, int &n_ins, int &n_ops)
+{
+    int ip = rows - 1, c = L - 1;
+    int ins = 0, cnt = 0;
+    int cur = best;
+    while (ip >= tv.pad || c >= 0) {
+        int up = tv.D(ip - 1, c);
+        int code;
+        if (ip >= tv.pad && up + 1 == cur) { code = 1; ins++; ip--; cur = up; }
+        else {
+            int left = tv.D(ip, c - 1);
+            if (c >= 0 && left + 1 == cur) { code = 2; c--; cur = left; }
+            else {
+                int ul = tv.D(ip - 1, c - 1);
+                code = (ul == cur) ? 0 : 3;
+                ip--; c--; cur = ul;
+            }
+        }
+        if (ops && cnt < ops_cap) ops[cnt] = (uint8_t)code;
+        cnt++;
+    }
+    n_ins = ins; n_ops = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lane-per-pair kernel: W words per lane in registers
+// ------------------------------------------------------------------------------------------------
+template <int W, int MODE>
+__global__ void __launch_bounds__(256) myers_lane(MyArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int64_t gwave = (int64_t)blockIdx.x * waves_per_block + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * waves_per_block;
+    const int S = a.S;
+    uint64_t *peq = lds + (size_t)wave * S * W * 64 + lane; // word (sym, b) at peq[(sym*W + b)*64]
+    constexpr int ROWS = 64 * W;
+
+    for (int64_t base = a.begin + gwave * 64; base < a.end; base += nwaves * 64) {
+        Item it = setup_item<MODE>(a, base + lane);
+        if (MODE == MODE_FWD_EXACT) {
+            if (!__any(it.valid)) continue;
+        }
+        const int pad = ROWS - it.m;
+        // ---- Peq into LDS (lane-private words: no synchronisation needed) ----
+        {
+            const uint64_t padfill_on = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ~(uint64_t)0 : 0;
+            for (int s = 0; s < S; s++) {
+#pragma unroll
+                for (int b = 0; b < W; b++) peq[(s * W + b) * 64] = pad_mask(pad, b) & padfill_on;
+            }
+            int mmax = wave_max_i32(it.valid ? it.m : 0);
+            for (int i0 = 0; i0 < mmax; i0 += 8) {
+                if (it.valid && i0 < it.m) {
+                    uint64_t chunk = load8(it.q + i0);
+                    int lim = it.m - i0; if (lim > 8) lim = 8;
+                    for (int u = 0; u < lim; u++) {
+                        int code = (int)((chunk >> (8 * u)) & 0xff);
+                        int bit = pad + i0 + u;
+                        peq[(code * W + (bit >> 6)) * 64] |= ((uint64_t)1) << (bit & 63);
+                    }
+                }
+            }
+        }
+        uint64_t Pv[W], Mv[W];
+        int32_t sc[W];
+#pragma unroll
+        for (int b = 0; b < W; b++) {
+            Pv[b] = ~pad_mask(pad, b); Mv[b] = 0;
+            int v = 64 * (b + 1) - pad; sc[b] = v > 0 ? v : 0;
+        }
+        const uint32_t top_hp = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? 0u : 1u;
+        int32_t score = it.m;
+        int32_t best = 0x3fffffff, cnt = 0, lim = it.k, last = -1;
+        int32_t *out = nullptr; int32_t out_cap = 0;
+        if (MODE == MODE_FWD) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
+        if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
+        uint64_t *tP = nullptr, *tM = nullptr; int32_t *tS = nullptr;
+        if (MODE == MODE_NW) {
+            tP = a.trP + gwave * a.region + lane; tM = a.trM + gwave * a.region + lane; tS = a.trS + gwave * a.region + lane;
+        }
+        const int n = it.valid ? it.n : 0;
+        const int nmax = wave_max_i32(n);
+        uint64_t tw = 0, tnext = (n > 0) ? load8(it.t) : 0;
+        for (int j = 0; j < nmax; j++) {
+            if ((j & 7) == 0) {
+                tw = tnext;
+                if (j + 8 < n) tnext = load8(it.t + j + 8);
+            }
+            if (j < n) {
+                const int code = (int)(tw & 0xff);
+                const uint64_t *pe = peq + (size_t)code * (W * 64);
+                uint32_t hp = top_hp, hm = 0;
+#pragma unroll
+                for (int b = 0; b < W; b++) {
+                    word_step(Pv[b], Mv[b], pe[b * 64], hp, hm);
+                    if (MODE == MODE_NW) {
+                        sc[b] += (int32_t)hp - (int32_t)hm;
+                        int64_t o = ((int64_t)j * W + b) * 64;
+                        tP[o] = Pv[b]; tM[o] = Mv[b]; tS[o] = sc[b];
+                    }
+                }
+                score += (int32_t)hp - (int32_t)hm;
+                if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
+                    if (score <= lim) {
+                        if (score < best) { best = score; cnt = 0; lim = score; }
+                        if (cnt < out_cap) out[cnt] = j;
+                        cnt++;
+                    }
+                } else if (MODE == MODE_REV) {
+                    if (score <= it.best) last = j;
+                }
+            }
+            tw >>= 8;
+        }
+        if (MODE == MODE_FWD) {
+            if (it.valid) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
+        } else if (MODE == MODE_REV) {
+            if (it.valid) a.loc_start[base + lane] = a.loc_end[base + lane] - last;
+        } else if (MODE == MODE_NW) {
+            __threadfence();
+            if (it.valid) {
+                TraceView tv{tP, tM, tS, 64, (int64_t)W * 64, pad};
+                uint8_t *ops = nullptr; int ops_cap = 0;
+                if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
+                int ins, nops;
+                traceback(tv, ROWS, it.n, it.best, ops, ops_cap, ins, nops);
+                a.first_ins[it.pair] = ins;
+                if (a.n_ops) a.n_ops[it.pair] = nops;
+            }
+            __threadfence();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lane-group kernel: G lanes per pair, W words per lane, skewed (anti-diagonal) schedule
+// ------------------------------------------------------------------------------------------------
+template <int G, int W, int MODE>
+__global__ void __launch_bounds__(64) myers_group(MyArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    constexpr int P = 64 / G;    // pairs per wave
+    constexpr int NB = G * W;    // words per pair
+    constexpr int ROWS = 64 * NB;
+    const int lane = threadIdx.x;
+    const int g = lane % G, p = lane / G;
+    const int S = a.S;
+    uint64_t *peq = lds + (size_t)p * S * NB; // word (sym, blk) at peq[sym*NB + blk]
+
+    for (int64_t base = a.begin + (int64_t)blockIdx.x * P; base < a.end; base += (int64_t)gridDim.x * P) {
+        Item it = setup_item<MODE>(a, base + p);
+        if (MODE == MODE_FWD_EXACT) {
+            if (!__any(it.valid)) continue;
+        }
+        const int pad = ROWS - it.m;
+        const uint64_t padfill_on = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ~(uint64_t)0 : 0;
+        uint64_t Pv[W], Mv[W];
+        int32_t sc[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const int blk = g * W + w;
+            for (int s = 0; s < S; s++) peq[s * NB + blk] = pad_mask(pad, blk) & padfill_on;
+            if (it.valid) {
+                for (int bit = 0; bit < 64; bit++) {
+                    int i = 64 * blk + bit - pad;
+                    if (i >= 0 && i < it.m) peq[(int)it.q[i] * NB + blk] |= ((uint64_t)1) << bit;
+                }
+            }
+            Pv[w] = ~pad_mask(pad, blk); Mv[w] = 0;
+            int v = 64 * (blk + 1) - pad; sc[w] = v > 0 ? v : 0;
+        }
+        const uint32_t top_hp = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? 0u : 1u;
+        int32_t score = it.m;
+        int32_t best = 0x3fffffff, cnt = 0, lim = it.k, last = -1;
+        int32_t *out = nullptr; int32_t out_cap = 0;
+        if (MODE == MODE_FWD) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
+        if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
+        uint64_t *tP = nullptr, *tM = nullptr; int32_t *tS = nullptr;
+        if (MODE == MODE_NW) {
+            int64_t slot = (int64_t)blockIdx.x * P + p;
+            tP = a.trP + slot * a.region; tM = a.trM + slot * a.region; tS = a.trS + slot * a.region;
+        }
+        const int n = it.valid ? it.n : 0;
+        const int nmax = wave_max_i32(n);
+        const int steps = nmax + G - 1;
+        uint32_t hp_out = 0, hm_out = 0;
+        for (int t = 0; t < steps; t++) {
+            uint32_t hp = __shfl_up(hp_out, 1, 64), hm = __shfl_up(hm_out, 1, 64);
+            if (g == 0) { hp = top_hp; hm = 0; }
+            const int col = t - g;
+            if (col >= 0 && col < n) {
+                const int code = (int)it.t[col];
+                const uint64_t *pe = peq + (size_t)code * NB + g * W;
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    word_step(Pv[w], Mv[w], pe[w], hp, hm);
+                    if (MODE == MODE_NW) {
+                        sc[w] += (int32_t)hp - (int32_t)hm;
+                        int64_t o = (int64_t)col * NB + g * W + w;
+                        tP[o] = Pv[w]; tM[o] = Mv[w]; tS[o] = sc[w];
+                    }
+                }
+                hp_out = hp; hm_out = hm;
+                if (g == G - 1) {
+                    score += (int32_t)hp - (int32_t)hm;
+                    if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
+                        if (score <= lim) {
+                            if (score < best) { best = score; cnt = 0; lim = score; }
+                            if (cnt < out_cap) out[cnt] = col;
+                            cnt++;
+                        }
+                    } else if (MODE == MODE_REV) {
+                        if (score <= it.best) last = col;
+                    }
+                }
+            }
+        }
+        if (MODE == MODE_FWD) {
+            if (it.valid && g == G - 1) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
+        } else if (MODE == MODE_REV) {
+            if (it.valid && g == G - 1) a.loc_start[base + p] = a.loc_end[base + p] - last;
+        } else if (MODE == MODE_NW) {
+            __threadfence();
+            if (it.valid && g == 0) {
+                TraceView tv{tP, tM, tS, 1, (int64_t)NB, pad};
+                uint8_t *ops = nullptr; int ops_cap = 0;
+                if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
+                int ins, nops;
+                traceback(tv, ROWS, it.n, it.best, ops, ops_cap, ins, nops);
+                a.first_ins[it.pair] = ins;
+                if (a.n_ops) a.n_ops[it.pair] = nops;
+            }
+            __threadfence();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helper kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_reverse(const uint8_t *src, uint8_t *dst, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[n - 1 - i];
+}
+
+// packed[i] = (hit << 40) | nloc  so one scan yields both CSR offsets
+__global__ void k_pack(const int32_t *ed, const int32_t *nloc, uint64_t *packed, int32_t n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) packed[i] = (ed[i] >= 0 ? (((uint64_t)1) << 40) : 0) | (uint64_t)(uint32_t)nloc[i];
+}
+
+constexpr int SCAN_BLOCK = 1024;
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_block(const uint64_t *in, uint64_t *out, uint64_t *blocksum, int64_t n)
+{
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint64_t v = i < n ? in[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+        uint64_t add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (i < n) out[i] = sh[threadIdx.x] - v; // exclusive
+    if (threadIdx.x == SCAN_BLOCK - 1 && blocksum) blocksum[blockIdx.x] = sh[threadIdx.x];
+}
+__global__ void k_scan_add(uint64_t *out, const uint64_t *blockoff, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    if (i < n) out[i] += blockoff[blockIdx.x];
+}
+// splits the scanned packed values; entry n holds the totals
+__global__ void k_unpack(const uint64_t *scanned, const uint64_t *packed, int64_t *loc_off, int64_t *hit_off, int32_t n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t LOW = (((uint64_t)1) << 40) - 1;
+    if (i < n) {
+        loc_off[i] = (int64_t)(scanned[i] & LOW);
+        hit_off[i] = (int64_t)(scanned[i] >> 40);
+        if (i == n - 1) {
+            uint64_t tot = scanned[i] + packed[i];
+            loc_off[n] = (int64_t)(tot & LOW);
+            hit_off[n] = (int64_t)(tot >> 40);
+        }
+    }
+}
+__global__ void k_gather_bounds(const int64_t *loc_off, const int64_t *hit_off, const int64_t *pos, int64_t *out, int np)
+{
+    int i = threadIdx.x;
+    if (i < np) { out[2 * i] = loc_off[pos[i]]; out[2 * i + 1] = hit_off[pos[i]]; }
+}
+// CSR fill: end columns kept in the first-pass slots, owner pair of every location, hit list
+__global__ void k_fill(const int32_t *ed, const int32_t *nloc, const int32_t *slots, int slot_cap,
+                       const int64_t *loc_off, const int64_t *hit_off,
+                       int32_t *loc_end, int32_t *loc_pair, int32_t *hit_pairs, int32_t n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = nloc[i];
+    int64_t o = loc_off[i];
+    for (int a = 0; a < c; a++) {
+        loc_pair[o + a] = i;
+        if (c <= slot_cap) loc_end[o + a] = slots[(int64_t)i * slot_cap + a];
+    }
+    if (ed[i] >= 0) hit_pairs[hit_off[i]] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct ClassDef { int G, W; };
+// rows = 64*G*W ascending
+const ClassDef kClasses[] = {
+    {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 7}, {1, 8},
+    {16, 1}, {16, 2}, {64, 1}, {64, 2}, {64, 4}, {64, 8},
+};
+constexpr int kNumClasses = sizeof(kClasses) / sizeof(kClasses[0]);
+constexpr int kMaxQuery = 64 * 64 * 8;
+constexpr int kMaxSymbols = 16;
+constexpr size_t kArenaPad = 64;
+
+template <int W, int MODE> hipError_t launch_lane(ultra_ctx *ctx, const MyArgs &a, int64_t items, int max_waves)
+{
+    int S = a.S;
+    size_t per_wave = (size_t)S * W * 64 * sizeof(uint64_t);
+    int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(64 * 1024) / per_wave));
+    size_t shmem = per_wave * wpb;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)myers_lane<W, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    int64_t waves = (items + 63) / 64;
+    if (max_waves > 0 && waves > max_waves) waves = max_waves;
+    int64_t blocks = (waves + wpb - 1) / wpb;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL((myers_lane<W, MODE>), dim3((unsigned)blocks), dim3(64 * wpb), shmem, ctx->stream, a);
+    return hipGetLastError();
+}
+
+template <int G, int W, int MODE> hipError_t launch_group(ultra_ctx *ctx, const MyArgs &a, int64_t items, int max_blocks)
+{
+    constexpr int P = 64 / G;
+    size_t shmem = (size_t)P * a.S * G * W * sizeof(uint64_t);
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)myers_group<G, W, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    int64_t blocks = (items + P - 1) / P;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL((myers_group<G, W, MODE>), dim3((unsigned)blocks), dim3(64), shmem, ctx->stream, a);
+    return hipGetLastError();
+}
+
+template <int MODE> hipError_t launch_class(ultra_ctx *ctx, int cls, const MyArgs &a, int64_t items, int max_par)
+{
+    switch (cls) {
+    case 0: return launch_lane<1, MODE>(ctx, a, items, max_par);
+    case 1: return launch_lane<2, MODE>(ctx, a, items, max_par);
+    case 2: return launch_lane<3, MODE>(ctx, a, items, max_par);
+    case 3: return launch_lane<4, MODE>(ctx, a, items, max_par);
+    case 4: return launch_lane<5, MODE>(ctx, a, items, max_par);
+    case 5: return launch_lane<6, MODE>(ctx, a, items, max_par);
+    case 6: return launch_lane<7, MODE>(ctx, a, items, max_par);
+    case 7: return launch_lane<8, MODE>(ctx, a, items, max_par);
+    case 8: return launch_group<16, 1, MODE>(ctx, a, items, max_par);
+    case 9: return launch_group<16, 2, MODE>(ctx, a, items, max_par);
+    case 10: return launch_group<64, 1, MODE>(ctx, a, items, max_par);
+    case 11: return launch_group<64, 2, MODE>(ctx, a, items, max_par);
+    case 12: return launch_group<64, 4, MODE>(ctx, a, items, max_par);
+    case 13: return launch_group<64, 8, MODE>(ctx, a, items, max_par);
+    }
+    return hipErrorInvalidValue;
+}
+
+int class_of(int m)
+{
+    for (int c = 0; c < kNumClasses; c++)
+        if (m <= 64 * kClasses[c].G * kClasses[c].W) return c;
+    return -1;
+}
+
+hipError_t device_scan(ultra_ctx *ctx, MyersState &st, int64_t n)
+{
+    // three-kernel exclusive scan of st.packed -> st.scanned (n <= 2^20 * 1024)
+    int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipError_t e;
+    if ((e = st.blocksum.ensure(sizeof(uint64_t) * (size_t)(2 * nb + 2 * SCAN_BLOCK))) != hipSuccess) return e;
+    uint64_t *bs = st.blocksum.as<uint64_t>();
+    uint64_t *bs2 = bs + nb;
+    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, st.packed.as<uint64_t>(),
+                       st.scanned.as<uint64_t>(), bs, n);
+    if (nb > 1) {
+        if (nb > (int64_t)SCAN_BLOCK * SCAN_BLOCK) return hipErrorInvalidValue;
+        int64_t nb2 = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        uint64_t *bs3 = bs2 + nb;
+        // scan of block sums (two levels are enough for n <= 2^30)
+        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ctx->stream, bs, bs2, bs3, nb);
+        if (nb2 > 1) {
+            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, bs3, bs3 + nb2, (uint64_t *)nullptr, nb2);
+            hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ctx->stream, bs2, bs3 + nb2, nb);
+        }
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, st.scanned.as<uint64_t>(), bs2, n);
+    }
+    return hipGetLastError();
+}
+
+} // namespace
+
+void ultra_myers_free(ultra_ctx *ctx)
+{
+    MyersState &st = ctx->my;
+    DevBuf *bufs[] = {&st.seq, &st.rseq, &st.qoff, &st.qlen, &st.toff, &st.tlen, &st.k, &st.ed, &st.nloc, &st.slots,
+                      &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
+                      &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+}
+
+int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
+                           const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
+                           const int32_t *k)
+{
+    MyersState &st = ctx->my;
+    st.staged = false; st.ran = false;
+    if (n_pairs < 0 || (n_pairs > 0 && (!arena || !q_off || !q_len || !t_off || !t_len || !k)))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_stage: null pointer or negative pair count");
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // validate + classify
+    std::vector<int> cls((size_t)n_pairs);
+    double cells = 0;
+    for (int32_t p = 0; p < n_pairs; p++) {
+        if (q_len[p] < 1 || t_len[p] < 1 || q_off[p] < 0 || t_off[p] < 0 ||
+            (uint64_t)q_off[p] + (uint64_t)q_len[p] > arena_len || (uint64_t)t_off[p] + (uint64_t)t_len[p] > arena_len)
+            return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_stage: pair " + std::to_string(p) +
+                                                    " has an empty sequence or offsets outside the arena");
+        int c = class_of(q_len[p]);
+        if (c < 0)
+            return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: query of pair " + std::to_string(p) + " is longer than " +
+                                                            std::to_string(kMaxQuery) + " bases");
+        cls[p] = c;
+        cells += (double)q_len[p] * (double)t_len[p];
+    }
+    // alphabet compaction: distinct bytes -> dense codes (comparisons stay byte-exact)
+    int code_of[256];
+    for (int i = 0; i < 256; i++) code_of[i] = -1;
+    std::vector<uint8_t> enc(arena_len + 2 * kArenaPad, 0);
+    int S = 0;
+    {
+        bool seen[256] = {false};
+        for (size_t i = 0; i < arena_len; i++) seen[arena[i]] = true;
+        for (int i = 0; i < 256; i++) if (seen[i]) code_of[i] = S++;
+        if (S > kMaxSymbols)
+            return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: more than 16 distinct symbols in the batch");
+        if (S == 0) S = 1;
+        for (size_t i = 0; i < arena_len; i++) enc[kArenaPad + i] = (uint8_t)code_of[arena[i]];
+    }
+    // order pairs by (class, target length) so that a wavefront's lanes run equally long
+    st.perm.resize((size_t)n_pairs);
+    for (int32_t p = 0; p < n_pairs; p++) st.perm[p] = p;
+    std::stable_sort(st.perm.begin(), st.perm.end(), [&](int32_t a, int32_t b) {
+        if (cls[a] != cls[b]) return cls[a] < cls[b];
+        return t_len[a] < t_len[b];
+    });
+    st.classes.clear();
+    st.h_qoff.resize(n_pairs); st.h_toff.resize(n_pairs); st.h_qlen.resize(n_pairs); st.h_tlen.resize(n_pairs); st.h_k.resize(n_pairs);
+    for (int32_t i = 0; i < n_pairs; i++) {
+        int32_t p = st.perm[i];
+        st.h_qoff[i] = q_off[p] + (int64_t)kArenaPad; st.h_toff[i] = t_off[p] + (int64_t)kArenaPad;
+        st.h_qlen[i] = q_len[p]; st.h_tlen[i] = t_len[p]; st.h_k[i] = k[p];
+        int c = cls[p];
+        if (st.classes.empty() || st.classes.back().G != kClasses[c].G || st.classes.back().W != kClasses[c].W) {
+            MyersClass mc; mc.G = kClasses[c].G; mc.W = kClasses[c].W; mc.pb = i; mc.pe = i; mc.max_t = 0;
+            mc.lb = mc.le = mc.hb = mc.he = 0;
+            st.classes.push_back(mc);
+        }
+        st.classes.back().pe = i + 1;
+        st.classes.back().max_t = std::max(st.classes.back().max_t, t_len[p]);
+    }
+    st.n_pairs = n_pairs; st.N = (int64_t)enc.size(); st.S = S; st.cells = cells;
+    const size_t np = (size_t)std::max(n_pairs, 1);
+    ULTRA_HIP_CHECK(ctx, st.seq.ensure(enc.size() + 16));
+    ULTRA_HIP_CHECK(ctx, st.rseq.ensure(enc.size() + 16));
+    ULTRA_HIP_CHECK(ctx, st.qoff.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.toff.ensure(np * 8));
+    ULTRA_HIP_CHECK(ctx, st.qlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.tlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.k.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.ed.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.nloc.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.firstins.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.nops.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.hitpairs.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.slots.ensure(np * 4 * (size_t)ctx->cfg.loc_slots));
+    ULTRA_HIP_CHECK(ctx, st.packed.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.scanned.ensure(np * 8));
+    ULTRA_HIP_CHECK(ctx, st.locoff.ensure((np + 1) * 8)); ULTRA_HIP_CHECK(ctx, st.hitoff.ensure((np + 1) * 8));
+    ULTRA_HIP_CHECK(ctx, st.bounds.ensure(64 * 8 * 4));
+    hipStream_t s = ctx->stream;
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.seq.p, enc.data(), enc.size(), hipMemcpyHostToDevice, s));
+    if (n_pairs > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.qoff.p, st.h_qoff.data(), np * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.toff.p, st.h_toff.data(), np * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.qlen.p, st.h_qlen.data(), np * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.tlen.p, st.h_tlen.data(), np * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.k.p, st.h_k.data(), np * 4, hipMemcpyHostToDevice, s));
+    }
+    {
+        int64_t n = st.N;
+        hipLaunchKernelGGL(k_reverse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st.seq.as<uint8_t>(), st.rseq.as<uint8_t>(), n);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // enc/h_* are host temporaries
+    for (auto &e : st.ev) if (!e) ULTRA_HIP_CHECK(ctx, hipEventCreate(&e));
+    st.staged = true;
+    return ULTRA_OK;
+}
+
+int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
+{
+    MyersState &st = ctx->my;
+    if (!st.staged) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_myers_run: no staged batch");
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int32_t n = st.n_pairs;
+    st.ran = false;
+    st.total_loc = st.total_hit = 0;
+    for (auto &m : st.ms) m = 0;
+    if (n == 0) { st.ran = true; return ULTRA_OK; }
+    MyArgs a;
+    memset(&a, 0, sizeof a);
+    a.seq = st.seq.as<uint8_t>(); a.rseq = st.rseq.as<uint8_t>(); a.N = st.N; a.S = st.S;
+    a.q_off = st.qoff.as<int64_t>(); a.q_len = st.qlen.as<int32_t>(); a.t_off = st.toff.as<int64_t>();
+    a.t_len = st.tlen.as<int32_t>(); a.k = st.k.as<int32_t>();
+    a.ed = st.ed.as<int32_t>(); a.nloc = st.nloc.as<int32_t>(); a.slots = st.slots.as<int32_t>(); a.slot_cap = ctx->cfg.loc_slots;
+    a.loc_off = st.locoff.as<int64_t>(); a.hit_pairs = st.hitpairs.as<int32_t>(); a.first_ins = st.firstins.as<int32_t>();
+    a.n_ops = st.nops.as<int32_t>();
+
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.firstins.p, 0, (size_t)n * 4, s));
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.nops.p, 0, (size_t)n * 4, s));
+    ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[0], s));
+    // ---- pass 1: forward HW ----
+    for (auto &mc : st.classes) {
+        a.begin = mc.pb; a.end = mc.pe;
+        int cls = class_of(64 * mc.G * mc.W);
+        ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD>(ctx, cls, a, mc.pe - mc.pb, 0));
+    }
+    // ---- CSR offsets ----
+    hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n);
+    ULTRA_HIP_CHECK(ctx, device_scan(ctx, st, n));
+    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, s, st.scanned.as<uint64_t>(), st.packed.as<uint64_t>(),
+                       st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), n);
+    {
+        // class boundaries (+ totals) to the host: one small copy, the only mid-batch synchronisation
+        std::vector<int64_t> pos;
+        for (auto &mc : st.classes) pos.push_back(mc.pb);
+        pos.push_back(n);
+        int npz = (int)pos.size();
+        int64_t *dpos = st.bounds.as<int64_t>();
+        int64_t *dout = dpos + 64;
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(dpos, pos.data(), npz * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_gather_bounds, dim3(1), dim3(64), 0, s, st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), dpos, dout, npz);
+        std::vector<int64_t> hb((size_t)npz * 2);
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb.data(), dout, npz * 16, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        for (size_t c = 0; c < st.classes.size(); c++) {
+            st.classes[c].lb = hb[2 * c]; st.classes[c].le = hb[2 * (c + 1)];
+            st.classes[c].hb = hb[2 * c + 1]; st.classes[c].he = hb[2 * (c + 1) + 1];
+        }
+        st.total_loc = hb[2 * (npz - 1)]; st.total_hit = hb[2 * (npz - 1) + 1];
+    }
+    const size_t nl = (size_t)std::max<int64_t>(st.total_loc, 1);
+    ULTRA_HIP_CHECK(ctx, st.locend.ensure(nl * 4)); ULTRA_HIP_CHECK(ctx, st.locstart.ensure(nl * 4)); ULTRA_HIP_CHECK(ctx, st.locpair.ensure(nl * 4));
+    a.loc_end = st.locend.as<int32_t>(); a.loc_start = st.locstart.as<int32_t>(); a.loc_pair = st.locpair.as<int32_t>();
+    hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, a.slots, a.slot_cap, a.loc_off,
+                       st.hitoff.as<int64_t>(), a.loc_end, st.locpair.as<int32_t>(), st.hitpairs.as<int32_t>(), n);
+    ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots ----
+    for (auto &mc : st.classes) {
+        a.begin = mc.pb; a.end = mc.pe;
+        int cls = class_of(64 * mc.G * mc.W);
+        ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD_EXACT>(ctx, cls, a, mc.pe - mc.pb, 0));
+    }
+    ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
+    // ---- pass 2: start positions ----
+    for (auto &mc : st.classes) {
+        if (mc.le <= mc.lb) continue;
+        a.begin = mc.lb; a.end = mc.le;
+        int cls = class_of(64 * mc.G * mc.W);
+        ULTRA_HIP_CHECK(ctx, launch_class<MODE_REV>(ctx, cls, a, mc.le - mc.lb, 0));
+    }
+    ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
+    // ---- pass 3: first-location traceback ----
+    a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
+    a.ops_off = want_ops ? st.opsoff.as<int64_t>() : nullptr;
+    const size_t budget = (size_t)6 << 30; // trace scratch budget (bytes)
+    for (auto &mc : st.classes) {
+        if (mc.he <= mc.hb) continue;
+        int cls = class_of(64 * mc.G * mc.W);
+        const int NB = mc.G * mc.W;
+        int64_t Lmax = std::min<int64_t>(mc.max_t, (int64_t)2 * 64 * NB);
+        int64_t items = mc.he - mc.hb;
+        int64_t region, units; // entries per unit (wave for lane kernels, pair slot for group kernels)
+        int max_par;
+        if (mc.G == 1) {
+            region = Lmax * mc.W * 64;
+            int64_t waves = (items + 63) / 64;
+            units = std::min<int64_t>(waves, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 20))));
+            units = std::min<int64_t>(units, (int64_t)ctx->prop.multiProcessorCount * 16);
+            max_par = (int)units;
+        } else {
+            const int P = 64 / mc.G;
+            region = Lmax * NB;
+            int64_t blocks = (items + P - 1) / P;
+            int64_t b = std::min<int64_t>(blocks, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 20 * P))));
+            b = std::min<int64_t>(b, (int64_t)ctx->prop.multiProcessorCount * 8);
+            max_par = (int)b;
+            units = b * P;
+        }
+        size_t entries = (size_t)region * (size_t)units;
+        // lane kernels round the grid up to whole blocks: leave room for up to 3 extra waves
+        size_t slack = (mc.G == 1) ? (size_t)region * 4 : 0;
+        ULTRA_HIP_CHECK(ctx, st.trace.ensure((entries + slack) * 20 + 64));
+        a.trP = st.trace.as<uint64_t>();
+        a.trM = a.trP + (entries + slack);
+        a.trS = (int32_t *)(a.trM + (entries + slack));
+        a.region = region; a.Lmax = (int32_t)Lmax;
+        a.begin = mc.hb; a.end = mc.he;
+        ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx, cls, a, items, max_par));
+        // the scratch buffer may be re-sized by the next class: wait before reuse
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    }
+    ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[3], s));
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[0], st.ev[0], st.ev[1]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[1], st.ev[1], st.ev[2]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[2], st.ev[2], st.ev[3]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[3], st.ev[0], st.ev[3]));
+    st.ran = true;
+    return ULTRA_OK;
+}

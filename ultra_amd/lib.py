@@ -1,0 +1,223 @@
+"""ctypes binding of libultra_hip.so (include/ultra_hip.h).
+
+The library is the product: there is no CPU fallback.  Loading fails loudly when the shared
+object is missing, and creating a Context fails loudly when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libultra_hip.so")
+
+ULTRA_OK = 0
+ULTRA_E_CAPACITY = -3
+
+_ERR_NAMES = {-1: "ULTRA_E_ARG", -2: "ULTRA_E_HIP", -3: "ULTRA_E_CAPACITY", -4: "ULTRA_E_UNSUPPORTED",
+              -5: "ULTRA_E_NODEVICE", -6: "ULTRA_E_STATE"}
+
+EXPORTS = [
+    "ultra_cfg_default", "ultra_ctx_create", "ultra_ctx_destroy", "ultra_last_error", "ultra_device_count",
+    "ultra_device_info", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
+    "ultra_myers_last_timing", "ultra_chain_mams_batch",
+]
+
+
+class UltraError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "%s (%d): %s" % (_ERR_NAMES.get(code, "ULTRA_E_?"), code, msg))
+        self.code = code
+
+
+class Cfg(C.Structure):
+    _fields_ = [("chain_switch_n", C.c_int32), ("overlap_small", C.c_int32), ("overlap_large", C.c_int32),
+                ("loc_slots", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libultra_hip.so; raises OSError if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libultra_hip.so not found at %s - build it with `make -C ultra_amd/csrc` "
+                      "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32p, i64p, u8p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+    lib.ultra_cfg_default.argtypes = [C.POINTER(Cfg)]
+    lib.ultra_cfg_default.restype = None
+    lib.ultra_ctx_create.argtypes = [C.c_int, C.POINTER(Cfg), C.POINTER(vp)]
+    lib.ultra_ctx_destroy.argtypes = [vp]
+    lib.ultra_ctx_destroy.restype = None
+    lib.ultra_last_error.argtypes = [vp]
+    lib.ultra_last_error.restype = C.c_char_p
+    lib.ultra_device_count.argtypes = []
+    lib.ultra_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ultra_myers_hw_batch.argtypes = [vp, u8p, C.c_size_t, C.c_int32, i64p, i32p, i64p, i32p, i32p,
+                                         i32p, i32p, i64p, i32p, i32p, C.c_int64, i64p, i32p, u8p, i64p, i32p]
+    lib.ultra_myers_stage.argtypes = [vp, u8p, C.c_size_t, C.c_int32, i64p, i32p, i64p, i32p, i32p]
+    lib.ultra_myers_run.argtypes = [vp]
+    lib.ultra_myers_fetch.argtypes = [vp, i32p, i32p, i64p, i32p, i32p, C.c_int64, i64p, i32p]
+    lib.ultra_myers_last_timing.argtypes = [vp, f64p, C.POINTER(C.c_float)]
+    lib.ultra_chain_mams_batch.argtypes = [vp, C.c_int32, i64p, i32p, i32p, i32p, i32p, f64p, C.c_int32, C.c_int32,
+                                           C.c_int32, i32p, i32p, f64p]
+    _lib = lib
+    return lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _arr(v, dt):
+    return np.ascontiguousarray(v, dtype=dt)
+
+
+class Context(object):
+    """One GPU context (ultra_ctx). Not thread-safe; use one per GPU/process."""
+
+    def __init__(self, device=0, cfg=None):
+        self.lib = load()
+        self._h = C.c_void_p()
+        c = Cfg()
+        self.lib.ultra_cfg_default(C.byref(c))
+        if cfg:
+            for k, v in cfg.items():
+                setattr(c, k, v)
+        self.cfg = c
+        rc = self.lib.ultra_ctx_create(int(device), C.byref(c), C.byref(self._h))
+        if rc != ULTRA_OK:
+            raise UltraError(rc, "ultra_ctx_create(device=%d) failed: no usable gfx950 device" % device)
+
+    def close(self):
+        if self._h:
+            self.lib.ultra_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != ULTRA_OK:
+            raise UltraError(rc, (self.lib.ultra_last_error(self._h) or b"").decode())
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        ncu, clk = C.c_int(), C.c_int()
+        self._check(self.lib.ultra_device_info(self._h, name, 64, C.byref(ncu), C.byref(clk)))
+        return {"arch": name.value.decode(), "n_cu": ncu.value, "clock_khz": clk.value}
+
+    # ---- Myers -------------------------------------------------------------------------------
+    def myers_hw_batch(self, arena, q_off, q_len, t_off, t_len, k, want_ops=False):
+        """Returns dict(ed, n_loc, loc_off, loc_start, loc_end, first_ins[, ops, ops_off, n_ops])."""
+        arena = _arr(arena, np.uint8)
+        q_off, t_off = _arr(q_off, np.int64), _arr(t_off, np.int64)
+        q_len, t_len, k = _arr(q_len, np.int32), _arr(t_len, np.int32), _arr(k, np.int32)
+        n = len(q_len)
+        ed = np.zeros(n, np.int32); nl = np.zeros(n, np.int32); fi = np.zeros(n, np.int32)
+        lo = np.zeros(n + 1, np.int64)
+        ops = ops_off = n_ops = None
+        if want_ops:
+            cap = q_len.astype(np.int64) + np.minimum(t_len.astype(np.int64), 2 * q_len.astype(np.int64))
+            ops_off = np.zeros(n + 1, np.int64); np.cumsum(cap, out=ops_off[1:])
+            ops = np.zeros(max(int(ops_off[-1]), 1), np.uint8)
+            n_ops = np.zeros(n, np.int32)
+        loc_cap = max(4 * n, 16)
+        need = C.c_int64(0)
+        first = True
+        while True:
+            ls = np.zeros(loc_cap, np.int32); le = np.zeros(loc_cap, np.int32)
+            if first:
+                rc = self.lib.ultra_myers_hw_batch(self._h, _ptr(arena, C.c_uint8), arena.size, n,
+                                                   _ptr(q_off, C.c_int64), _ptr(q_len, C.c_int32),
+                                                   _ptr(t_off, C.c_int64), _ptr(t_len, C.c_int32), _ptr(k, C.c_int32),
+                                                   _ptr(ed, C.c_int32), _ptr(nl, C.c_int32), _ptr(lo, C.c_int64),
+                                                   _ptr(ls, C.c_int32), _ptr(le, C.c_int32), loc_cap, C.byref(need),
+                                                   _ptr(fi, C.c_int32), _ptr(ops, C.c_uint8), _ptr(ops_off, C.c_int64),
+                                                   _ptr(n_ops, C.c_int32))
+                if rc == ULTRA_E_CAPACITY and need.value > loc_cap and not want_ops:
+                    loc_cap = int(need.value); first = False
+                    continue
+                if rc == ULTRA_E_CAPACITY and need.value > loc_cap:
+                    loc_cap = int(need.value)  # edit scripts live only inside the one-shot call: run it again
+                    continue
+            else:
+                rc = self.lib.ultra_myers_fetch(self._h, _ptr(ed, C.c_int32), _ptr(nl, C.c_int32), _ptr(lo, C.c_int64),
+                                                _ptr(ls, C.c_int32), _ptr(le, C.c_int32), loc_cap, C.byref(need),
+                                                _ptr(fi, C.c_int32))
+            self._check(rc)
+            break
+        out = {"ed": ed, "n_loc": nl, "loc_off": lo, "loc_start": ls[:int(lo[-1])], "loc_end": le[:int(lo[-1])],
+               "first_ins": fi}
+        if want_ops:
+            out.update(ops=ops, ops_off=ops_off, n_ops=n_ops)
+        return out
+
+    def myers_stage(self, arena, q_off, q_len, t_off, t_len, k):
+        arena = _arr(arena, np.uint8)
+        q_off, t_off = _arr(q_off, np.int64), _arr(t_off, np.int64)
+        q_len, t_len, k = _arr(q_len, np.int32), _arr(t_len, np.int32), _arr(k, np.int32)
+        self._staged_n = len(q_len)
+        self._check(self.lib.ultra_myers_stage(self._h, _ptr(arena, C.c_uint8), arena.size, len(q_len),
+                                               _ptr(q_off, C.c_int64), _ptr(q_len, C.c_int32), _ptr(t_off, C.c_int64),
+                                               _ptr(t_len, C.c_int32), _ptr(k, C.c_int32)))
+
+    def myers_run(self):
+        self._check(self.lib.ultra_myers_run(self._h))
+
+    def myers_timing(self):
+        cells = C.c_double()
+        ms = (C.c_float * 4)()
+        self._check(self.lib.ultra_myers_last_timing(self._h, C.byref(cells), ms))
+        return cells.value, [ms[i] for i in range(4)]
+
+    def myers_fetch(self):
+        n = self._staged_n
+        ed = np.zeros(n, np.int32); nl = np.zeros(n, np.int32); fi = np.zeros(n, np.int32)
+        lo = np.zeros(n + 1, np.int64)
+        loc_cap = max(4 * n, 16)
+        need = C.c_int64(0)
+        while True:
+            ls = np.zeros(loc_cap, np.int32); le = np.zeros(loc_cap, np.int32)
+            rc = self.lib.ultra_myers_fetch(self._h, _ptr(ed, C.c_int32), _ptr(nl, C.c_int32), _ptr(lo, C.c_int64),
+                                            _ptr(ls, C.c_int32), _ptr(le, C.c_int32), loc_cap, C.byref(need),
+                                            _ptr(fi, C.c_int32))
+            if rc == ULTRA_E_CAPACITY and need.value > loc_cap:
+                loc_cap = int(need.value)
+                continue
+            self._check(rc)
+            break
+        return {"ed": ed, "n_loc": nl, "loc_off": lo, "loc_start": ls[:int(lo[-1])], "loc_end": le[:int(lo[-1])],
+                "first_ins": fi}
+
+    # ---- chaining ----------------------------------------------------------------------------
+    def chain_mams_batch(self, inst_off, x, y, c, d, val, solver=0, overlap_small=-1, overlap_large=-1):
+        inst_off = _arr(inst_off, np.int64)
+        x, y, c, d = _arr(x, np.int32), _arr(y, np.int32), _arr(c, np.int32), _arr(d, np.int32)
+        val = _arr(val, np.float64)
+        ni = len(inst_off) - 1
+        idx = np.zeros(max(len(c), 1), np.int32); ln = np.zeros(max(ni, 1), np.int32)
+        value = np.zeros(max(ni, 1), np.float64)
+        self._check(self.lib.ultra_chain_mams_batch(self._h, ni, _ptr(inst_off, C.c_int64), _ptr(x, C.c_int32),
+                                                    _ptr(y, C.c_int32), _ptr(c, C.c_int32), _ptr(d, C.c_int32),
+                                                    _ptr(val, C.c_double), solver, overlap_small, overlap_large,
+                                                    _ptr(idx, C.c_int32), _ptr(ln, C.c_int32), _ptr(value, C.c_double)))
+        return idx, ln[:ni], value[:ni]
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on device LOCAL_RANK (or 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx
