@@ -73,3 +73,30 @@ def make_mams(rng, n, readlen, ties):
     rows.sort(key=lambda r: r[1])
     a = np.array([r[:4] for r in rows], np.int32).reshape(-1, 4)
     return a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy(), a[:, 3].copy(), np.array([r[4] for r in rows], np.float64)
+
+
+# ---- golden fixtures (tests/golden/*.json) ---------------------------------------------------------
+def load_golden_world(rec):
+    """Rebuilds the five index dictionaries of a classify_golden.json world record, in the layout the
+    reference's hot path reads (keys = array('L',[chr,start,stop]).tobytes(), values = flat array('L'))."""
+    from array import array
+
+    def key(t):
+        return array('L', [int(v) for v in t]).tobytes()
+    seg = {key(r[:3]): r[3] for r in rec["segments"]}
+    flank = {key(r[:3]): r[3] for r in rec["flanks"]}
+    p2s = {key(k): array('L', flat) for k, flat in rec["parts_to_segments"]}
+    s2g = {key(k): set(g) for k, g in rec["segment_to_gene"]}
+    g2s = {g: array('L', flat) for g, flat in rec["gene_to_small_segments"]}
+    return seg, flank, p2s, s2g, g2s
+
+
+def golden_solution(rows):
+    from ultra_amd.synth import Mem
+    return [Mem(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5]), r[6]) for r in rows]
+
+
+def mam_rows(sol):
+    """Canonical comparable form of a MAM tuple list (val as IEEE-754 hex)."""
+    return [[int(m.x), int(m.y), int(m.c), int(m.d), float(m.val).hex(), int(m.j), int(m.min_segment_length),
+             str(m.mam_id), int(m.ref_chr_id)] for m in sol]
