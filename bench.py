@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the MAM stage (uLTRA's per-read alignment core) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads B] [--preset ont_cdna]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of B synthetic (read, NAM chain) instances
+whose candidate (segment, read) pairs are already resident in HBM: Myers forward / start / traceback
+kernels, MAM materialisation, chaining.  Workload = BASELINE.json configs[2] in its self-generated
+synthetic form (ONT cDNA-like reads, ~7 % errors, ~1 kb): GRCh38/GENCODE do not
+exist offline.  Reads are independent, so with N > 1 every rank runs its own shard (weak scaling, no
+data-path collective; torch.distributed is used for the barrier and the max-over-ranks time only).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (Myers forward class with the most time): integer-VALU bound,
+                achieved = 0.75 int32-op/cell * cells / HIP-event time of that kernel
+  cpu_baseline  the CPU oracle (oracle/, "port") timed on a bounded sample on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+OPS_PER_CELL = 0.75          # SURVEY.md section 8d convention: 48 int32 VALU ops per 64-cell block column
+PEAK_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: max clock
+LANES_PER_CU_CLK = 128       # 4 SIMD-32 per CU (MI355X_MICROARCH.md "CU = 4 x SIMD-32")
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=8192, help="reads (instances) per step and per GPU")
+    ap.add_argument("--preset", default="ont_cdna", choices=["ont_cdna", "isoseq", "ont_drna"])
+    ap.add_argument("--genes", type=int, default=1500)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="0 = min(16, available cores)")
+    ap.add_argument("--check", type=int, default=64, help="instances of the last step verified against the oracle")
+    return ap.parse_args()
+
+
+# ---- CPU baseline (oracle; runs BEFORE anything touches the GPU so that fork is safe) -----------------
+_CPU = {}
+
+
+def _cpu_worker(rng):
+    from oracle import classify_port
+    idx, insts, min_acc = _CPU["idx"], _CPU["insts"], _CPU["min_acc"]
+    t0 = time.perf_counter()
+    for i in rng:
+        read, sol, _ = insts[i]
+        classify_port.classify(sol, *idx, read, None, min_acc)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(idx, insts, min_acc, seconds, workers, cells_per_read):
+    import multiprocessing as mp
+    from oracle import cport
+    cport.lib()
+    _CPU.update(idx=idx, insts=insts, min_acc=min_acc)
+    # calibrate on a few instances, then size the sample to `seconds` of wall time
+    t = _cpu_worker(range(min(32, len(insts))))
+    per = t / min(32, len(insts))
+    n = int(max(workers * 8, seconds / per * workers))   # wraps around the batch when it is smaller than the sample
+    chunks = [[i % len(insts) for i in range(j, n, workers)] for j in range(workers)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(workers) as pool:
+        pool.map(_cpu_worker, chunks)
+    wall = time.perf_counter() - t0
+    return {"value": n / wall, "unit": "reads/s", "cores": workers, "kind": "port",
+            "sample": "%d reads of the same synthetic batch through oracle/classify_port.py + liboracle.so "
+                      "(C Myers bit-vector + chainers), %d fork workers, %.1f s wall" % (n, workers, wall),
+            "gcups": n * cells_per_read / wall * 1e-9}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from ultra_amd import synth
+    from ultra_amd import classify_read_with_mams as stage
+
+    # ---- synthetic workload (same world on every rank, a different read shard per rank) ----------
+    P = synth.PRESETS[args.preset]
+    w = synth.make_world(seed=20241008, n_genes=args.genes, n_chr=8)
+    idx = w.index()
+    insts = synth.make_instances(w, args.reads, seed=1000 + rank, preset=args.preset)
+    batch = stage.prepare_batch([(sol, read) for read, sol, _ in insts], *idx)
+    cells = batch.cells
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        workers = args.cpu_workers or max(1, min(16, len(os.sched_getaffinity(0))))
+        cpu = cpu_baseline(idx, insts, P["min_acc"], args.cpu_seconds, workers, cells / float(len(insts)))
+
+    # ---- GPU ---------------------------------------------------------------------------------------
+    import torch
+    import torch.distributed as dist
+    from ultra_amd import lib
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ctx = lib.Context(local)
+    info = ctx.device_info()
+    stage.stage_batch(ctx, batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stage.run_staged(ctx, P["min_acc"])
+    class_ms = {}
+    fwd_ms = rev_ms = tb_ms = all_ms = 0.0
+    build_ms = chain_ms = gather_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stage.run_staged(ctx, P["min_acc"])
+        _, ms = ctx.myers_timing()
+        fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]
+        mm = ctx.mam_timing()
+        build_ms += mm[0]; chain_ms += mm[1]; gather_ms += mm[2]
+        for key, (c, t) in ctx.myers_class_timing().items():
+            a = class_ms.setdefault(key, [0.0, 0.0, 0])
+            a[0] += c; a[1] += t; a[2] += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # results back to the host (PCIe; outside the timed region, reported separately)
+    t1 = time.perf_counter()
+    res = ctx.mam_fetch()
+    fetch_s = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    out = stage.results_to_python(batch, res)
+    topy_s = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(len(insts)), float(cells)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        reads_all, cells_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        reads_all, cells_all = float(len(insts)), float(cells)
+
+    # ---- parity spot check of the timed output (oracle = checker only) ---------------------------
+    checked = 0
+    if rank == 0 and args.check > 0:
+        import struct
+        from oracle import classify_port
+        for i in range(0, len(insts), max(1, len(insts) // args.check)):
+            read, sol, _ = insts[i]
+            want = classify_port.classify(sol, *idx, read, None, P["min_acc"])
+            g = out[i]
+            ok = (want[0] == g[0] and struct.pack("d", float(want[1])) == struct.pack("d", float(g[1]))
+                  and tuple(tuple(m) for m in want[2]) == tuple(tuple(m) for m in g[2]))
+            if not ok:
+                raise SystemExit("bench.py: instance %d differs from the oracle - refusing to report a number" % i)
+            checked += 1
+
+    if rank == 0:
+        K = args.steps
+        peak_ops = info["n_cu"] * LANES_PER_CU_CLK * PEAK_CLOCK_GHZ * 1e9
+        dom = max(class_ms.items(), key=lambda kv: kv[1][1]) if class_ms else None
+        roof = None
+        if dom:
+            (G, Wd), (c, ms, launches) = dom
+            ops_per_launch = OPS_PER_CELL * c / launches
+            dur = ms / launches * 1e-3
+            achieved = ops_per_launch / dur * 1e-12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "valu_int32", "kernel": "myers forward G=%d W=%d" % (G, Wd), "achieved": achieved,
+                    "peak": peak_ops * 1e-12, "unit": "Tops/s", "frac": achieved / (peak_ops * 1e-12),
+                    "traffic": traffic, "cells_per_launch": c / launches, "avg_launch_ms": ms / launches,
+                    "ops_per_cell": OPS_PER_CELL,
+                    "hbm": {"algorithmic_bytes_per_step": batch.algorithmic_bytes, "achieved_GBs":
+                            batch.algorithmic_bytes / (all_ms / K * 1e-3) * 1e-9 if all_ms > 0 else None,
+                            "peak_GBs": HBM_PEAK_GBS}}
+        line = {
+            "metric": "reads aligned/sec (whole node), MAM stage: Myers HW matching + MAM chaining",
+            "value": reads_all * K / elapsed, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 bit-vectors / int32 scores (Myers), f64 (chaining)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] synthetic form: ONT-cDNA-like reads (%s, err %.2f, ~%d bp), "
+                                   "%d reads/GPU/step, %d genes synthetic annotation" % (args.preset, P["err"], P["len_mean"], args.reads, args.genes),
+                       "reads_per_gpu_per_step": args.reads, "pairs_per_step_per_gpu": batch.n_pairs,
+                       "cells_per_step_per_gpu": cells, "parallelism": "reads sharded, %d rank(s), no collective" % world},
+            "myers_gcups_forward": cells_all * K / (fwd_ms * 1e-3) * 1e-9 / 1.0 if fwd_ms > 0 else None,
+            "myers_gcups_all_passes": cells_all * K / (all_ms * 1e-3) * 1e-9 if all_ms > 0 else None,
+            "stage_ms_per_step": {"myers_forward": fwd_ms / K, "myers_starts": rev_ms / K, "myers_traceback": tb_ms / K,
+                                  "myers_total": all_ms / K, "mam_build": build_ms / K, "chain": chain_ms / K,
+                                  "chain_gather": gather_ms / K},
+            "outside_timed_region": {"fetch_results_pcie_ms": fetch_s * 1e3, "python_tuples_ms": topy_s * 1e3,
+                                     "reads_per_s_incl_fetch": reads_all / world / (elapsed / K + fetch_s),
+                                     "chain_rows_fetched": int(res["chain_off"][-1])},
+            "device": info, "parity_checked_instances": checked,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

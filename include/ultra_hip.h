@@ -103,6 +103,11 @@ int ultra_myers_fetch(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
  * stage: [0] forward (distance + end positions), [1] reverse (start positions), [2] traceback,
  * [3] everything (first launch to last completion).  Measured with HIP events on the ctx stream. */
 int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[4]);
+/* Per size class of the last _run (a class = one kernel instantiation: G lanes per pair x W 64-row
+ * words per lane): forward-pass cells and device milliseconds of that class's forward launch.
+ * Fills up to cap entries, *n_classes = number of classes of the batch. For roofline reports. */
+int ultra_myers_class_timing(const ultra_ctx *ctx, int32_t cap, int32_t *G, int32_t *W, double *cells, float *fwd_ms,
+                             int32_t *n_classes);
 
 /*
  * Batched MAM colinear chaining.  Replaces
@@ -123,6 +128,69 @@ int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
                            const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
                            const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
                            int32_t *chain_idx, int32_t *chain_len, double *value);
+
+/*
+ * The whole MAM stage of a batch of (read, location) instances in one call, results identical to
+ *     classify_read_with_mams.main(solution, ..., read_seq, warning_log_file, min_acc)
+ *         -> (non_covered_regions, value, mam_solution)          (modules/classify_read_with_mams.py:406-594)
+ * for every instance: all edlib calls (ultra_myers_hw_batch above), add_segment_to_mam (:303-402) on their
+ * results, phase A / first-last-exon reduction / phase B with its de-duplication (:440-523), the
+ * outermost-partial filter (:530-547), the stable sort by y (:553-555), the solver switch (:560-575)
+ * and the chainers (ultra_chain_mams_batch above) run on the GPU without intermediate host copies.
+ * What stays on the host is the dictionary-driven candidate enumeration (:180-300, :441-523 loop
+ * order), whose result is the input below.
+ *
+ * Candidates of instance i are cand[inst_cand_off[i] .. inst_cand_off[i+1]) in the reference's
+ * emission order: full segments (kind 0, by start), full flanks (1, by start), then for every
+ * partially hit segment the pair (2 = "_partial_segment_start" variant, 3 = "_partial_segment_end"
+ * variant; the library applies the reference's if/elif), then partial flanks (4 start, 5 end).
+ *   cand_e_start/e_stop     coordinates of the FULL segment or flank (x, y of its MAMs)
+ *   cand_pair               pair index of the segment-in-read search (edlib call :312 / :353), -1 if none
+ *                           (segment narrower than 5 bp); its k must be (2*min(m,n))/5, or 0 for widths 5..8
+ *   cand_pair_contained     pair index of the read-in-segment search (:377), -1 if e_stop-e_start < 0.8*len(read)
+ *   cand_seq_len            length of the sequence handed to add_segment_to_mam (partial variants: the cut piece)
+ *   cand_seq_id             equal for two candidates of one instance iff their sequences are equal strings
+ *                           (the reference's segm_already_tried sets, :479-523)
+ *   inst_first_part_stop / inst_last_part_start   values of :194-221 (2^32 / 0 when no part was hit)
+ */
+typedef struct ultra_mam_input {
+    const uint8_t *arena; size_t arena_len;
+    int32_t n_pairs;
+    const int64_t *q_off; const int32_t *q_len; const int64_t *t_off; const int32_t *t_len; const int32_t *k;
+    int32_t n_cand;
+    const uint8_t *cand_kind;
+    const int32_t *cand_e_start, *cand_e_stop, *cand_pair, *cand_pair_contained, *cand_seq_len, *cand_seq_id;
+    int32_t n_inst;
+    const int64_t *inst_cand_off;       /* [n_inst + 1] */
+    const int32_t *inst_read_len;
+    const int64_t *inst_first_part_stop, *inst_last_part_start;
+} ultra_mam_input;
+
+/*
+ * Caller-sized outputs.  Per instance: value (-1 for an empty MAM instance, :577), n_mam (size of the
+ * filtered MAM instance), chain_off (CSR, n_inst + 1).  Per chain element (the reference's mam_solution,
+ * in chain order): x, y, c, d, val, min_segment_length, the candidate index it came from (the host
+ * rebuilds mam_id = str(segm_id) + label from it) and j = its index in the instance's sorted MAM list.  mam_* (optional, all NULL or all set, with mam_off):
+ * every instance's complete MAM list sorted by y, for parity tests on MAM sets.
+ */
+typedef struct ultra_mam_output {
+    double *value; int32_t *n_mam; int64_t *chain_off;
+    int64_t chain_cap;
+    int32_t *chain_x, *chain_y, *chain_c, *chain_d; double *chain_val; int32_t *chain_msl, *chain_cand, *chain_j;
+    int64_t mam_cap; int64_t *mam_off;
+    int32_t *mam_x, *mam_y, *mam_c, *mam_d; double *mam_val; int32_t *mam_msl, *mam_cand;
+} ultra_mam_output;
+
+int ultra_mam_batch(ultra_ctx *ctx, const ultra_mam_input *in, double min_acc, ultra_mam_output *out);
+/* The same in three steps (host -> HBM once, then any number of device-only runs, then results back).
+ * After _run, ultra_mam_sizes gives the sizes _fetch needs (sum of chain lengths, sum of n_mam). */
+int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in);
+int ultra_mam_run(ultra_ctx *ctx, double min_acc);
+int ultra_mam_sizes(const ultra_ctx *ctx, int64_t *n_chain_total, int64_t *n_mam_total);
+int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out);
+/* Device milliseconds of the last _run beyond the Myers passes (ultra_myers_last_timing):
+ * [0] MAM materialisation, [1] chaining, [2] chain compaction. */
+int ultra_mam_last_timing(const ultra_ctx *ctx, float ms[3]);
 
 #ifdef __cplusplus
 }

@@ -142,9 +142,9 @@ def plan_candidates(solution, parts_to_segments, segment_to_gene, gene_to_small_
     return full_segments, partial_segments, full_flanks, partial_flanks, first_part_stop, last_part_start
 
 
-def classify(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
-             gene_to_small_segments, read_seq, warning_log_file, min_acc):
-    """main (:406-594): returns (non_covered_regions, value, mam_solution)."""
+def mam_instance(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
+                 gene_to_small_segments, read_seq, min_acc):
+    """The filtered MAM list of main, sorted by y with j renumbered (:419-555)."""
     full_segments, partial_segments, full_flanks, partial_flanks, first_part_stop, last_part_start = \
         plan_candidates(solution, parts_to_segments, segment_to_gene, gene_to_small_segments)
 
@@ -201,7 +201,14 @@ def classify(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segm
             if not ("_start" in m.mam_id and m.c > p_start) and not ("_end" in m.mam_id and m.d < p_end)]
 
     mams.sort(key=lambda m: m.y)
-    mams = [m._replace(j=j) for j, m in enumerate(mams)]
+    return [m._replace(j=j) for j, m in enumerate(mams)]
+
+
+def classify(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
+             gene_to_small_segments, read_seq, warning_log_file, min_acc):
+    """main (:406-594): returns (non_covered_regions, value, mam_solution)."""
+    mams = mam_instance(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
+                        gene_to_small_segments, read_seq, min_acc)
     if not mams:
         return [], -1, tuple()
 

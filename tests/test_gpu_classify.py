@@ -1,16 +1,51 @@
-"""GPU parity of the whole MAM stage: ultra_amd.classify_read_with_mams.main_batch (HIP Myers +
-HIP chaining through the C ABI) vs the CPU restatement of the reference's main()."""
+"""GPU parity of the whole MAM stage: ultra_amd.classify_read_with_mams (fused HIP pipeline through
+the C ABI: Myers -> MAM lists -> chaining) vs (a) the golden vectors produced by the reference's own
+module and (b) the CPU oracle on larger seeded batches."""
+import json
+import os
 import struct
 
 import numpy as np
 import pytest
 
+from tests import helpers
+
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "classify_golden.json")
 
 
 def _same(a, b):
     return (a[0] == b[0] and struct.pack("d", float(a[1])) == struct.pack("d", float(b[1]))
             and tuple(tuple(m) for m in a[2]) == tuple(tuple(m) for m in b[2]))
+
+
+def test_main_batch_matches_reference_golden_vectors(ctx):
+    from ultra_amd import classify_read_with_mams as stage
+    gold = json.load(open(GOLD))
+    n = 0
+    for w in gold["worlds"]:
+        idx = helpers.load_golden_world(w["world"])
+        by_acc = {}
+        for inst in w["instances"]:
+            by_acc.setdefault(inst["min_acc"], []).append(inst)
+        for min_acc, insts in by_acc.items():
+            got = stage.main_batch([(helpers.golden_solution(i["solution"]), i["read"]) for i in insts], *idx,
+                                   min_acc=min_acc, ctx=ctx)
+            for inst, (gaps, value, mams) in zip(insts, got):
+                assert [int(g) for g in gaps] == inst["non_covered_regions"]
+                assert float(value).hex() == inst["value"]
+                assert helpers.mam_rows(mams) == inst["mam_solution"]
+                n += 1
+    assert n >= 140
+
+
+def test_add_segment_to_mam_matches_reference_golden_vectors(ctx):
+    from ultra_amd import classify_read_with_mams as stage
+    gold = json.load(open(GOLD))
+    for c in gold["add_segment_to_mam"]:
+        out = []
+        stage.add_segment_to_mam(c["read"], 3, c["seq"], c["e_start"], c["e_stop"], c["segm_id"], out, c["min_acc"], c["label"], ctx=ctx)
+        assert helpers.mam_rows(out) == c["mams"]
 
 
 @pytest.mark.parametrize("preset,n", [("ont_cdna", 300), ("isoseq", 120), ("ont_drna", 200)])
@@ -31,23 +66,96 @@ def test_main_batch_matches_oracle(ctx, preset, n):
     assert bad == 0
 
 
-def test_single_instance_signatures(ctx):
+@pytest.mark.parametrize("kw", [{}, {"small_exon_frac": 0.4, "split_frac": 0.7}])
+def test_full_mam_lists_match_oracle(ctx, kw):
+    """MAM SETS, not only the chosen chains: every instance's filtered, sorted MAM list."""
     from oracle import classify_port
     from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import synth
+    w = synth.make_world(seed=23, n_genes=40, **kw)
+    insts = synth.make_instances(w, 150, seed=6, preset="ont_drna", flank_start_prob=0.4, flank_end_prob=0.4)
+    idx = w.index()
+    batch = stage.prepare_batch([(sol, read) for read, sol, _ in insts], *idx)
+    stage.stage_batch(ctx, batch)
+    stage.run_staged(ctx, 0.6)
+    res = ctx.mam_fetch(want_all=True)
+    lists = stage.mam_lists_to_python(batch, res)
+    n_mams = 0
+    for (read, sol, _), got in zip(insts, lists):
+        want = classify_port.mam_instance(sol, *idx, read, 0.6)
+        assert helpers.mam_rows(got) == helpers.mam_rows(want)
+        n_mams += len(want)
+    assert n_mams > 1000
+    # a second run over the same staged batch gives the same bytes (no state leaks between runs)
+    stage.run_staged(ctx, 0.6)
+    res2 = ctx.mam_fetch(want_all=True)
+    for k in res:
+        assert np.array_equal(res[k], res2[k]), k
+
+
+def test_low_complexity_reads_many_locations(ctx):
+    """Repeats give long location lists, repeated starts and 5-8 bp exact segments with many hits."""
+    from array import array
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd.synth import Mem, key_of
+    rng = np.random.RandomState(3)
+    insts, seg, flank, p2s, s2g, g2s = [], {}, {}, {}, {}, {"g": array('L')}
+    pos = 1000
+    segs = []
+    for i in range(24):
+        ln = int(rng.choice([5, 6, 7, 8, 9, 12, 20, 40, 90]))
+        s = helpers.rand_seq(rng, ln, "AC" if i % 2 else "A")
+        k = key_of(1, pos, pos + ln)
+        seg[k] = s; s2g[k] = {"g"}; p2s[k] = array('L', [1, pos, pos + ln]); g2s["g"].extend([1, pos, pos + ln])
+        segs.append((pos, pos + ln, s))
+        pos += ln + 300
+    for r in range(40):
+        read = helpers.rand_seq(rng, int(rng.randint(150, 500)), "AC" if r % 3 else "A")
+        a, b, s = segs[int(rng.randint(0, len(segs)))]
+        sol = [Mem(a, b - 1, 0, b - a - 1, b - a, 0, "1^%d^%d" % (a, b))]
+        insts.append((read, sol))
+    idx = (seg, flank, p2s, s2g, g2s)
+    got = stage.main_batch([(sol, read) for read, sol in insts], *idx, min_acc=0.6, ctx=ctx)
+    for (read, sol), g in zip(insts, got):
+        assert _same(classify_port.classify(sol, *idx, read, None, 0.6), g)
+
+
+def test_single_instance_signatures(ctx):
+    from oracle import classify_port, cport
+    from ultra_amd import classify_read_with_mams as stage
     from ultra_amd import colinear_solver, edlib_shim, synth
-    from oracle import cport
     w = synth.make_world(seed=22, n_genes=20)
     read, sol, _ = synth.make_instances(w, 1, seed=5)[0]
     idx = w.index()
     got = stage.main(sol, *idx, read, None, 0.6)
     assert _same(classify_port.classify(sol, *idx, read, None, 0.6), got)
+    assert stage.main_batch([], *idx, min_acc=0.6, ctx=ctx) == []
     # edlib-shaped call
     r = edlib_shim.align("ACGTTGCA", "TTACGTAGCATT", mode="HW", task="path", k=3)
     o = cport.hw_align("ACGTTGCA", "TTACGTAGCATT", 3)
     assert r["editDistance"] == o["editDistance"] and r["locations"] == o["locations"] and r["cigar"] == o["cigar"]
     assert edlib_shim.align("AAAAAAAA", "CCCCCCCCCC", mode="HW", task="path", k=2)["editDistance"] == -1
+    r = edlib_shim.align("ACTG", "CACTRT", mode="HW", task="path")   # edlib's published README example
+    assert (r["editDistance"], r["locations"], r["cigar"]) == (1, [(1, 3), (1, 4)], "3=1I")
     # chainers with the reference's signatures
     mams = list(got[2])
     if mams:
         sol_q, val_q, _ = colinear_solver.read_coverage_mam_score(mams, overlap_threshold=20)
         assert len(sol_q) >= 1
+
+
+def test_bad_candidate_lists_fail_loudly(ctx):
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import lib, synth
+    w = synth.make_world(seed=22, n_genes=10)
+    insts = synth.make_instances(w, 4, seed=5)
+    batch = stage.prepare_batch([(sol, read) for read, sol, _ in insts], *w.index())
+    bad = dict(batch.packed)
+    bad["cand_pair"] = batch.packed["cand_pair"].copy(); bad["cand_pair"][0] = batch.n_pairs + 5
+    with pytest.raises(lib.UltraError):
+        ctx.mam_stage(bad)
+    bad = dict(batch.packed)
+    bad["cand_kind"] = batch.packed["cand_kind"].copy(); bad["cand_kind"][0] = 3
+    with pytest.raises(lib.UltraError):
+        ctx.mam_stage(bad)

@@ -8,10 +8,10 @@ Mirrors /root/reference/modules/classify_read_with_mams.py:
                                                                                (:303-402)
 plus `main_batch`, which is what the restaged align_single calls: every (read, location) instance
 of a batch is planned on the host (dict/set logic whose iteration order fixes tie order, kept in
-Python exactly as SURVEY.md section 7.3 item 3 asks), all candidate (segment, read) pairs of all
-instances go to the GPU in ONE Myers batch (phase-B partial candidates speculatively), the MAM
-lists are materialised from the returned distances/locations, and all instances are chained in ONE
-GPU chaining batch.
+Python exactly as SURVEY.md section 7.3 item 3 asks) and packed into flat arrays; ONE call of the
+fused C-ABI entry point (ultra_mam_stage/_run/_fetch) then does everything else on the GPU: all
+Myers searches (phase-B partial candidates speculatively), MAM materialisation, filters, the sort
+by y and the chaining.  Only the chosen chains come back.
 
 There is no CPU fallback: without libultra_hip.so / a gfx950 device every call raises.
 """
@@ -143,10 +143,11 @@ def plan_instance(solution, ref_segment_sequences, ref_flank_sequences, parts_to
 
 
 class PairList(object):
-    """Flat (query, target, k) pair list over a byte arena, deduplicating identical sequences."""
+    """Flat (query, target, k) pair list over a byte arena; identical sequences and identical pairs
+    are stored once."""
 
     def __init__(self):
-        self.chunks, self.size, self.where = [], 0, {}
+        self.chunks, self.size, self.where, self.pair_of = [], 0, {}, {}
         self.q_off, self.q_len, self.t_off, self.t_len, self.k = [], [], [], [], []
 
     def put(self, seq):
@@ -161,9 +162,15 @@ class PairList(object):
         return off
 
     def add(self, query, target, k):
-        self.q_off.append(self.put(query)); self.q_len.append(len(query))
-        self.t_off.append(self.put(target)); self.t_len.append(len(target))
-        self.k.append(int(k))
+        qo, to, k = self.put(query), self.put(target), int(k)
+        key = (qo, len(query), to, len(target), k)
+        hit = self.pair_of.get(key)
+        if hit is not None:
+            return hit
+        self.q_off.append(qo); self.q_len.append(len(query))
+        self.t_off.append(to); self.t_len.append(len(target))
+        self.k.append(k)
+        self.pair_of[key] = len(self.k) - 1
         return len(self.k) - 1
 
     def arena(self):
@@ -176,6 +183,8 @@ def _queue_pairs(pairs, read, cand):
     seq = cand.seq
     if len(seq) == 0 or len(read) == 0:
         return
+    if cand.kind >= PART_SEG_START and len(seq) <= 5:
+        return  # partial pieces of at most 5 bases are never aligned (:488, :497, :514, :520)
     if width >= 5:
         if width >= 9:
             cand.pair = pairs.add(seq, read, 0.4 * min(len(read), len(seq)))
@@ -185,100 +194,105 @@ def _queue_pairs(pairs, read, cand):
         cand.pair_contained = pairs.add(read, seq, 0.4 * min(len(read), len(seq)))
 
 
-def _accuracy(res, p):
-    """edlib_alignment + cigar_to_accuracy (:71-119) from (first location, ed, insertions)."""
-    lo = int(res["loc_off"][p])
-    span = int(res["loc_end"][lo]) - int(res["loc_start"][lo]) + 1
-    ins = int(res["first_ins"][p])
-    return (span - int(res["ed"][p]) + ins) / float(span + ins)
+class Batch(object):
+    """A planned batch: the candidate plans (host objects, needed to name the MAMs afterwards) and the
+    flat arrays of ultra_mam_input."""
+    __slots__ = ("plans", "packed", "n_pairs", "n_inst", "cells", "algorithmic_bytes")
 
 
-def _emit(res, read, cand, out, min_acc):
-    """add_segment_to_mam (:303-402) on GPU results."""
-    width = cand.e_stop - cand.e_start
-    name = str(cand.ident) + LABELS[cand.kind]
-    p = cand.pair
-    if p >= 0:
-        ed = int(res["ed"][p])
-        lo, hi = int(res["loc_off"][p]), int(res["loc_off"][p + 1])
-        if width >= 9:
-            if ed >= 0:
-                acc = _accuracy(res, p)
-                if acc > min_acc:
-                    seen, last_score = set(), 0
-                    for a in range(lo, hi):
-                        s, e = int(res["loc_start"][a]), int(res["loc_end"][a])
-                        span = e - s + 1
-                        score = max((span - ed) / span, acc) * span
-                        if s in seen and score <= last_score:
-                            continue
-                        out.append(mam(cand.e_start, cand.e_stop, s, e, score, 0, span, name, cand.chr_id))
-                        seen.add(s)
-                        last_score = score
-        elif ed == 0:
-            seen = set()
-            n = len(cand.seq)
-            for a in range(lo, hi):
-                s, e = int(res["loc_start"][a]), int(res["loc_end"][a])
-                if s in seen:
-                    continue
-                out.append(mam(cand.e_start, cand.e_stop, s, e, n, n, 0, name, cand.chr_id))
-                seen.add(s)
-    p = cand.pair_contained
-    if p >= 0 and int(res["ed"][p]) >= 0:
-        acc = _accuracy(res, p)
-        lo = int(res["loc_off"][p])
-        span = int(res["loc_end"][lo]) - int(res["loc_start"][lo]) + 1
-        if acc > min_acc:
-            out.append(mam(cand.e_start, cand.e_stop, 0, len(read) - 1, acc * span, 0, span, name, cand.chr_id))
+def pack_plans(plans):
+    """Flattens candidate plans into the arrays of ultra_mam_input (include/ultra_hip.h)."""
+    pairs = PairList()
+    kind, e0, e1, pr, prc, sl, sid, coff, rl, fps, lps = [], [], [], [], [], [], [], [0], [], [], []
+    for plan in plans:
+        ids = {}
+        for cand in plan.cands:
+            cand.pair = cand.pair_contained = -1
+            _queue_pairs(pairs, plan.read, cand)
+            kind.append(cand.kind); e0.append(cand.e_start); e1.append(cand.e_stop)
+            pr.append(cand.pair); prc.append(cand.pair_contained)
+            sl.append(len(cand.seq)); sid.append(ids.setdefault(cand.seq, len(ids)))
+        coff.append(len(kind))
+        rl.append(len(plan.read)); fps.append(plan.first_part_stop); lps.append(plan.last_part_start)
+    b = Batch()
+    b.plans = plans
+    b.packed = {
+        "arena": pairs.arena() if pairs.size else np.zeros(1, np.uint8),
+        "q_off": np.asarray(pairs.q_off, np.int64), "q_len": np.asarray(pairs.q_len, np.int32),
+        "t_off": np.asarray(pairs.t_off, np.int64), "t_len": np.asarray(pairs.t_len, np.int32),
+        "k": np.asarray(pairs.k, np.int32),
+        "cand_kind": np.asarray(kind, np.uint8), "cand_e_start": np.asarray(e0, np.int32), "cand_e_stop": np.asarray(e1, np.int32),
+        "cand_pair": np.asarray(pr, np.int32), "cand_pair_contained": np.asarray(prc, np.int32),
+        "cand_seq_len": np.asarray(sl, np.int32), "cand_seq_id": np.asarray(sid, np.int32),
+        "inst_cand_off": np.asarray(coff, np.int64), "inst_read_len": np.asarray(rl, np.int32),
+        "inst_first_part_stop": np.asarray(fps, np.int64), "inst_last_part_start": np.asarray(lps, np.int64),
+    }
+    b.n_pairs, b.n_inst = len(pairs.k), len(plans)
+    ql, tl = b.packed["q_len"].astype(np.int64), b.packed["t_len"].astype(np.int64)
+    b.cells = int(np.dot(ql, tl)) if b.n_pairs else 0
+    # SURVEY.md section 8d: m + n sequence bytes + 24 B descriptor + 16 B result header per pair
+    b.algorithmic_bytes = int(ql.sum() + tl.sum() + 40 * b.n_pairs)
+    return b
 
 
-def _materialise(plan, res, min_acc):
-    """Phase A, the first/last-exon reduction, phase B with its de-duplication, the outermost-partial
-    filter and the stable sort by y (:440-555)."""
-    read = plan.read
-    mams = []
-    cands = plan.cands
-    i = 0
-    while i < len(cands) and cands[i].kind in (FULL_SEGMENT, FULL_FLANK):
-        _emit(res, read, cands[i], mams, min_acc)
-        i += 1
-    if mams:
-        first_stop = max(plan.first_part_stop, min(m.y for m in mams))
-        last_start = min(plan.last_part_start, max(m.x for m in mams))
-    else:
-        first_stop = max(plan.first_part_stop, -1)
-        last_start = min(plan.last_part_start, 2 ** 32)
-    tried = set()
-    while i < len(cands) and cands[i].kind in (PART_SEG_START, PART_SEG_END):
-        a, b = cands[i], cands[i + 1]
-        i += 2
-        pick = a if a.e_stop <= first_stop else (b if last_start <= b.e_start else None)
-        if pick is not None and pick.seq not in tried and len(pick.seq) > 5:
-            _emit(res, read, pick, mams, min_acc)
-            tried.add(pick.seq)
-    tried = set()
-    while i < len(cands):
-        pick = cands[i]
-        i += 1
-        if pick.seq not in tried and len(pick.seq) > 5:
-            _emit(res, read, pick, mams, min_acc)
-            tried.add(pick.seq)
+def prepare_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
+                  gene_to_small_segments):
+    """Host packing of a batch of (solution, read_seq) instances: candidate enumeration + flat arrays."""
+    return pack_plans([plan_instance(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments,
+                                     segment_to_gene, gene_to_small_segments, read_seq)
+                       for solution, read_seq in instances])
 
-    p_start, p_end, min_d, max_c = 2 ** 32, 0, 2 ** 32, 0
-    for m in mams:
-        if "_start" in m.mam_id and m.c < p_start:
-            p_start = m.c
-        elif "_end" in m.mam_id and m.d > p_end:
-            p_end = m.d
-        if m.d < min_d:
-            min_d = m.d
-        if m.c > max_c:
-            max_c = m.c
-    p_start, p_end = min(p_start, min_d), max(p_end, max_c)
-    kept = [m for m in mams if not ("_start" in m.mam_id and m.c > p_start) and not ("_end" in m.mam_id and m.d < p_end)]
-    kept.sort(key=lambda m: m.y)
-    return [m._replace(j=j) for j, m in enumerate(kept)]
+
+def stage_batch(ctx, batch):
+    """Host -> HBM copy of the packed batch (once; run_staged may repeat)."""
+    ctx.mam_stage(batch.packed)
+
+
+def run_staged(ctx, min_acc):
+    """One device-only pass of the hot path over the staged batch (Myers -> MAMs -> chains)."""
+    ctx.mam_run(min_acc)
+
+
+def _mam_tuple(plan, res, prefix, r, j, cand_base):
+    cand = plan.cands[int(res[prefix + "cand"][r]) - cand_base]
+    msl = int(res[prefix + "msl"][r])
+    val = float(res[prefix + "val"][r])
+    if msl == 0:  # 5-8 bp exact segment: the reference stores the int len(exon_seq) (:357-367)
+        val = int(val)
+    return mam(int(res[prefix + "x"][r]), int(res[prefix + "y"][r]), int(res[prefix + "c"][r]), int(res[prefix + "d"][r]),
+               val, j, msl, str(cand.ident) + LABELS[cand.kind], cand.chr_id)
+
+
+def results_to_python(batch, res):
+    """(non_covered_regions, value, mam_solution) per instance from the fetched arrays (:577-594).
+    The j of a chain element is its index in the instance's sorted MAM list, as in the reference."""
+    out = []
+    coff = batch.packed["inst_cand_off"]
+    j_of = res.get("chain_j")
+    for i, plan in enumerate(batch.plans):
+        if int(res["n_mam"][i]) == 0:
+            out.append(([], -1, tuple()))
+            continue
+        a, b = int(res["chain_off"][i]), int(res["chain_off"][i + 1])
+        picked = tuple(_mam_tuple(plan, res, "chain_", r, int(j_of[r]), int(coff[i])) for r in range(a, b))
+        gaps = []
+        if picked:
+            gaps.append(picked[0].c)
+            for p, q in zip(picked[:-1], picked[1:]):
+                gaps.append(q.c - p.d - 1)
+            gaps.append(len(plan.read) - picked[-1].d)
+        out.append((gaps, float(res["value"][i]), picked))
+    return out
+
+
+def mam_lists_to_python(batch, res):
+    """Every instance's complete MAM list (sorted by y, j = position), from a want_all fetch."""
+    coff = batch.packed["inst_cand_off"]
+    out = []
+    for i, plan in enumerate(batch.plans):
+        a, b = int(res["mam_off"][i]), int(res["mam_off"][i + 1])
+        out.append([_mam_tuple(plan, res, "mam_", r, r - a, int(coff[i])) for r in range(a, b)])
+    return out
 
 
 def main_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
@@ -286,43 +300,18 @@ def main_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_to_s
     """instances: iterable of (solution, read_seq). Returns one (non_covered_regions, value,
     mam_solution) per instance, equal to what the reference's main() returns for each."""
     ctx = ctx or _lib.default_context()
-    plans, pairs = [], PairList()
-    for solution, read_seq in instances:
-        plan = plan_instance(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments,
-                             segment_to_gene, gene_to_small_segments, read_seq)
-        for cand in plan.cands:
-            _queue_pairs(pairs, read_seq, cand)
-        plans.append(plan)
-    if pairs.k:
-        res = ctx.myers_hw_batch(pairs.arena(), pairs.q_off, pairs.q_len, pairs.t_off, pairs.t_len, pairs.k)
-    else:
-        res = None
-    lists = [_materialise(plan, res, min_acc) for plan in plans]
-    off = np.zeros(len(lists) + 1, np.int64)
-    np.cumsum([len(l) for l in lists], out=off[1:])
-    flat = [m for l in lists for m in l]
-    if flat:
-        idx, ln, value = ctx.chain_mams_batch(off, [m.x for m in flat], [m.y for m in flat], [m.c for m in flat],
-                                              [m.d for m in flat], [float(m.val) for m in flat])
+    batch = prepare_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
+                          gene_to_small_segments)
+    if batch.n_inst == 0:
+        return []
+    stage_batch(ctx, batch)
+    run_staged(ctx, min_acc)
+    res = ctx.mam_fetch()
     if stats is not None:
-        stats["pairs"] = stats.get("pairs", 0) + len(pairs.k)
-        stats["cells"] = stats.get("cells", 0) + (int(np.dot(np.asarray(pairs.q_len, np.int64), np.asarray(pairs.t_len, np.int64))) if pairs.k else 0)
-        stats["mams"] = stats.get("mams", 0) + len(flat)
-    out = []
-    for i, (plan, l) in enumerate(zip(plans, lists)):
-        if not l:
-            out.append(([], -1, tuple()))
-            continue
-        o = int(off[i])
-        picked = tuple(l[j] for j in idx[o:o + int(ln[i])])
-        gaps = []
-        if picked:
-            gaps.append(picked[0].c)
-            for a, b in zip(picked[:-1], picked[1:]):
-                gaps.append(b.c - a.d - 1)
-            gaps.append(len(plan.read) - picked[-1].d)
-        out.append((gaps, float(value[i]), picked))
-    return out
+        stats["pairs"] = stats.get("pairs", 0) + batch.n_pairs
+        stats["cells"] = stats.get("cells", 0) + batch.cells
+        stats["mams"] = stats.get("mams", 0) + int(res["n_mam"].sum())
+    return results_to_python(batch, res)
 
 
 def main(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
@@ -333,12 +322,24 @@ def main(solution, ref_segment_sequences, ref_flank_sequences, parts_to_segments
                       segment_to_gene, gene_to_small_segments, min_acc)[0]
 
 
-def add_segment_to_mam(read_seq, ref_chr_id, exon_seq, e_start, e_stop, segm_id, mam_instance, min_acc, annot_label):
-    """Reference signature (:303): appends this candidate's MAMs to mam_instance."""
-    cand = Candidate(LABELS.index(annot_label), ref_chr_id, e_start, e_stop, exon_seq, segm_id, -1)
-    pairs = PairList()
-    _queue_pairs(pairs, read_seq, cand)
-    if not pairs.k:
-        return
-    res = _lib.default_context().myers_hw_batch(pairs.arena(), pairs.q_off, pairs.q_len, pairs.t_off, pairs.t_len, pairs.k)
-    _emit(res, read_seq, cand, mam_instance, min_acc)
+def add_segment_to_mam(read_seq, ref_chr_id, exon_seq, e_start, e_stop, segm_id, mam_instance, min_acc, annot_label,
+                       ctx=None):
+    """Reference signature (:303): appends this candidate's MAMs to mam_instance (j = 0 / len(exon_seq)
+    as the reference leaves it before main() renumbers).  One single-candidate GPU batch per call."""
+    ctx = ctx or _lib.default_context()
+    # a lone candidate is staged as kind 0 so that no instance-level filter applies; the label is only a name here
+    cand = Candidate(FULL_SEGMENT, ref_chr_id, e_start, e_stop, exon_seq, segm_id, -1)
+    plan = Plan()
+    plan.read, plan.cands, plan.first_part_stop, plan.last_part_start = read_seq, [cand], 2 ** 32, 0
+    batch = pack_plans([plan])
+    stage_batch(ctx, batch)
+    run_staged(ctx, min_acc)
+    res = ctx.mam_fetch(want_all=True)
+    name = str(segm_id) + annot_label
+    for r in range(int(res["mam_off"][1])):
+        msl = int(res["mam_msl"][r])
+        val = float(res["mam_val"][r])
+        if msl == 0:
+            val = int(val)
+        mam_instance.append(mam(int(res["mam_x"][r]), int(res["mam_y"][r]), int(res["mam_c"][r]), int(res["mam_d"][r]),
+                                val, val if msl == 0 else 0, msl, name, ref_chr_id))

@@ -48,6 +48,7 @@ void ultra_ctx_destroy(ultra_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ultra_myers_free(ctx);
     ultra_chain_free(ctx);
+    ultra_mam_free(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -82,6 +83,20 @@ int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[4])
     if (!ctx || !ctx->my.ran) return ULTRA_E_STATE;
     if (cells) *cells = ctx->my.cells;
     if (ms) for (int i = 0; i < 4; i++) ms[i] = ctx->my.ms[i];
+    return ULTRA_OK;
+}
+
+int ultra_myers_class_timing(const ultra_ctx *ctx, int32_t cap, int32_t *G, int32_t *W, double *cells, float *fwd_ms,
+                             int32_t *n_classes)
+{
+    if (!ctx || !ctx->my.ran) return ULTRA_E_STATE;
+    if (!n_classes || cap < 0 || (cap > 0 && (!G || !W || !cells || !fwd_ms))) return ULTRA_E_ARG;
+    int32_t n = (int32_t)ctx->my.classes.size();
+    *n_classes = n;
+    for (int32_t i = 0; i < n && i < cap; i++) {
+        const MyersClass &mc = ctx->my.classes[(size_t)i];
+        G[i] = mc.G; W[i] = mc.W; cells[i] = mc.cells; fwd_ms[i] = mc.fwd_ms;
+    }
     return ULTRA_OK;
 }
 

@@ -63,6 +63,7 @@ struct ChainArgs {
     int32_t thr;
     int32_t *idx, *len;
     double *value;
+    const int32_t *cnt;  // optional per-instance MAM count (nullptr: off[inst+1] - off[inst])
     const int32_t *list; // instance ids handled by this launch
     int32_t nlist;
     int32_t cap;         // LDS entries per wave (quadratic) / leaves (n log n)
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
     if (slot >= a.nlist) return;
     const int inst = a.list[slot];
     const int64_t o = a.off[inst];
-    const int n = (int)(a.off[inst + 1] - o);
+    const int n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
     const int cap = a.cap;
     uint8_t *base = lds_raw + (size_t)wave * cap * 20;
     double *sC = (double *)base;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
     if (slot >= a.nlist) return;
     const int inst = a.list[slot];
     const int64_t o = a.off[inst];
-    const int n = (int)(a.off[inst + 1] - o);
+    const int n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
     if (n <= 0) {
         if (lane == 0) { a.len[inst] = 0; a.value[inst] = -1.0; }
         return;
@@ -316,88 +317,73 @@ constexpr int kLdsBudget = 160 * 1024;
 void ultra_chain_free(ultra_ctx *ctx)
 {
     ChainState &ch = ctx->ch;
-    DevBuf *bufs[] = {&ch.off, &ch.x, &ch.y, &ch.c, &ch.d, &ch.val, &ch.idx, &ch.len, &ch.value, &ch.work};
+    DevBuf *bufs[] = {&ch.ioff, &ch.off, &ch.x, &ch.y, &ch.c, &ch.d, &ch.val, &ch.idx, &ch.len, &ch.value, &ch.work};
     for (DevBuf *b : bufs) b->release();
 }
 
-extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
-                                      const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
-                                      const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
-                                      int32_t *chain_idx, int32_t *chain_len, double *value)
+// Launches the chaining kernels for n_inst instances whose MAM arrays are already in device memory.
+// h_cnt: per-instance MAM counts on the host (used to pick solver / LDS sizes); d_cnt: the same on
+// the device, or nullptr when the counts are d_off[i+1] - d_off[i].  Asynchronous on ctx->stream;
+// *d_status (device int, zeroed here) is non-zero afterwards if an instance hit the reference's
+// "BUG" state.
+int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, const int64_t *d_off, const int32_t *d_cnt,
+                       const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
+                       int32_t solver, int32_t overlap_small, int32_t overlap_large,
+                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out)
 {
-    if (!ctx) return ULTRA_E_ARG;
-    if (n_inst < 0 || (n_inst > 0 && (!inst_off || !chain_len || !value)))
-        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: null pointer or negative instance count");
-    if (n_inst == 0) return ULTRA_OK;
-    if (solver < 0 || solver > 2) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: solver must be 0, 1 or 2");
+    if (solver < 0 || solver > 2) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: solver must be 0, 1 or 2");
     const int thr_s = overlap_small < 0 ? ctx->cfg.overlap_small : overlap_small;
     const int thr_l = overlap_large < 0 ? ctx->cfg.overlap_large : overlap_large;
-    const int64_t total = inst_off[n_inst];
-    if (inst_off[0] != 0 || total < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: inst_off must start at 0");
-    if (total > 0 && (!x || !y || !c || !d || !val || !chain_idx))
-        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: null MAM array");
     std::vector<int32_t> small, big, tree;
     int32_t max_big = 0, max_tree = 0;
     for (int32_t i = 0; i < n_inst; i++) {
-        int64_t n = inst_off[i + 1] - inst_off[i];
-        if (n < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: inst_off must be non-decreasing");
+        const int32_t n = h_cnt[i];
+        if (n < 0) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: negative instance size");
         bool use_tree = solver == 2 || (solver == 0 && n > ctx->cfg.chain_switch_n);
         if (use_tree && n > 0) {
-            if (thr_l < 1) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: n log n solver needs overlap threshold >= 1");
-            tree.push_back(i); max_tree = std::max<int32_t>(max_tree, (int32_t)n);
+            if (thr_l < 1) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: n log n solver needs overlap threshold >= 1");
+            tree.push_back(i); max_tree = std::max<int32_t>(max_tree, n);
         } else if (n <= kQuadSmall) small.push_back(i);
-        else { big.push_back(i); max_big = std::max<int32_t>(max_big, (int32_t)n); }
+        else { big.push_back(i); max_big = std::max<int32_t>(max_big, n); }
     }
     if ((size_t)max_big * 20 > (size_t)kLdsBudget)
-        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_chain_mams_batch: quadratic solver limited to 8192 MAMs per instance");
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "chaining: quadratic solver limited to 8192 MAMs per instance");
     int tree_leaves = 1;
     while (tree_leaves < max_tree + 1) tree_leaves <<= 1;
     size_t tree_lds = (size_t)tree_leaves * 16 + (size_t)((tree_leaves + 63) / 64) * 12 + 16;
     if (!tree.empty() && tree_lds > (size_t)kLdsBudget)
-        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_chain_mams_batch: n log n solver limited to 8191 MAMs per instance");
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "chaining: n log n solver limited to 8191 MAMs per instance");
 
-    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ChainState &ch = ctx->ch;
     hipStream_t s = ctx->stream;
-    const size_t nt = (size_t)std::max<int64_t>(total, 1), ni = (size_t)n_inst;
-    ULTRA_HIP_CHECK(ctx, ch.off.ensure((ni + 1) * 8 + (ni + 1) * 8 + ni * 4 + 64));
-    ULTRA_HIP_CHECK(ctx, ch.x.ensure(nt * 4)); ULTRA_HIP_CHECK(ctx, ch.y.ensure(nt * 4));
-    ULTRA_HIP_CHECK(ctx, ch.c.ensure(nt * 4)); ULTRA_HIP_CHECK(ctx, ch.d.ensure(nt * 4));
-    ULTRA_HIP_CHECK(ctx, ch.val.ensure(nt * 8)); ULTRA_HIP_CHECK(ctx, ch.idx.ensure(nt * 4));
-    ULTRA_HIP_CHECK(ctx, ch.len.ensure(ni * 4 + 16)); ULTRA_HIP_CHECK(ctx, ch.value.ensure(ni * 8));
-    // device layout of ch.off: inst_off | work_off | list
-    int64_t *d_off = ch.off.as<int64_t>();
-    int64_t *d_workoff = d_off + (ni + 1);
+    const size_t ni = (size_t)n_inst;
+    // device layout of ch.off: work_off | list | status
+    ULTRA_HIP_CHECK(ctx, ch.off.ensure((ni + 1) * 8 + ni * 4 + 64));
+    int64_t *d_workoff = ch.off.as<int64_t>();
     int32_t *d_list = (int32_t *)(d_workoff + (ni + 1));
-    int32_t *d_status = ch.len.as<int32_t>() + ni;
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_off, inst_off, (ni + 1) * 8, hipMemcpyHostToDevice, s));
-    if (total > 0) {
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.x.p, x, nt * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.y.p, y, nt * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.c.p, c, nt * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.d.p, d, nt * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.val.p, val, nt * 8, hipMemcpyHostToDevice, s));
-    }
+    int32_t *d_status = d_list + ni;
+    if (d_status_out) *d_status_out = d_status;
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_status, 0, 4, s));
-    std::vector<int32_t> list;
-    list.insert(list.end(), small.begin(), small.end());
-    list.insert(list.end(), big.begin(), big.end());
-    list.insert(list.end(), tree.begin(), tree.end());
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, s));
-    std::vector<int64_t> work_off(tree.size() + 1, 0);
+    ch.h_list.clear();
+    ch.h_list.insert(ch.h_list.end(), small.begin(), small.end());
+    ch.h_list.insert(ch.h_list.end(), big.begin(), big.end());
+    ch.h_list.insert(ch.h_list.end(), tree.begin(), tree.end());
+    if (!ch.h_list.empty())
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_list, ch.h_list.data(), ch.h_list.size() * 4, hipMemcpyHostToDevice, s));
+    ch.h_workoff.assign(tree.size() + 1, 0);
     for (size_t t = 0; t < tree.size(); t++) {
-        int64_t n = inst_off[tree[t] + 1] - inst_off[tree[t]];
+        int64_t n = h_cnt[tree[t]];
         int64_t bytes = (n + 1) * 12 + n * 16;
-        work_off[t + 1] = work_off[t] + ((bytes + 15) & ~(int64_t)15);
+        ch.h_workoff[t + 1] = ch.h_workoff[t] + ((bytes + 15) & ~(int64_t)15);
     }
     if (!tree.empty()) {
-        ULTRA_HIP_CHECK(ctx, ch.work.ensure((size_t)work_off.back() + 16));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_workoff, work_off.data(), work_off.size() * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, ch.work.ensure((size_t)ch.h_workoff.back() + 16));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_workoff, ch.h_workoff.data(), ch.h_workoff.size() * 8, hipMemcpyHostToDevice, s));
     }
     ChainArgs a;
     memset(&a, 0, sizeof a);
-    a.off = d_off; a.x = ch.x.as<int32_t>(); a.y = ch.y.as<int32_t>(); a.c = ch.c.as<int32_t>(); a.d = ch.d.as<int32_t>();
-    a.val = ch.val.as<double>(); a.idx = ch.idx.as<int32_t>(); a.len = ch.len.as<int32_t>(); a.value = ch.value.as<double>();
+    a.off = d_off; a.cnt = d_cnt; a.x = d_x; a.y = d_y; a.c = d_c; a.d = d_d;
+    a.val = d_val; a.idx = d_idx; a.len = d_len; a.value = d_value;
     a.status = d_status;
     if (!small.empty()) {
         a.thr = thr_s; a.list = d_list; a.nlist = (int32_t)small.size(); a.cap = kQuadSmall;
@@ -421,6 +407,50 @@ extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int6
         hipLaunchKernelGGL(chain_nlogn, dim3((unsigned)tree.size()), dim3(64), tree_lds, s, a);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
+    return ULTRA_OK;
+}
+
+extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
+                                      const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
+                                      const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
+                                      int32_t *chain_idx, int32_t *chain_len, double *value)
+{
+    if (!ctx) return ULTRA_E_ARG;
+    if (n_inst < 0 || (n_inst > 0 && (!inst_off || !chain_len || !value)))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: null pointer or negative instance count");
+    if (n_inst == 0) return ULTRA_OK;
+    const int64_t total = inst_off[n_inst];
+    if (inst_off[0] != 0 || total < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: inst_off must start at 0");
+    if (total > 0 && (!x || !y || !c || !d || !val || !chain_idx))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: null MAM array");
+    std::vector<int32_t> h_cnt((size_t)n_inst);
+    for (int32_t i = 0; i < n_inst; i++) {
+        int64_t n = inst_off[i + 1] - inst_off[i];
+        if (n < 0 || n > 0x7fffffff) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: inst_off must be non-decreasing");
+        h_cnt[(size_t)i] = (int32_t)n;
+    }
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ChainState &ch = ctx->ch;
+    hipStream_t s = ctx->stream;
+    const size_t nt = (size_t)std::max<int64_t>(total, 1), ni = (size_t)n_inst;
+    ULTRA_HIP_CHECK(ctx, ch.ioff.ensure((ni + 1) * 8));
+    ULTRA_HIP_CHECK(ctx, ch.x.ensure(nt * 4)); ULTRA_HIP_CHECK(ctx, ch.y.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.c.ensure(nt * 4)); ULTRA_HIP_CHECK(ctx, ch.d.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.val.ensure(nt * 8)); ULTRA_HIP_CHECK(ctx, ch.idx.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.len.ensure(ni * 4 + 16)); ULTRA_HIP_CHECK(ctx, ch.value.ensure(ni * 8));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.ioff.p, inst_off, (ni + 1) * 8, hipMemcpyHostToDevice, s));
+    if (total > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.x.p, x, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.y.p, y, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.c.p, c, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.d.p, d, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.val.p, val, nt * 8, hipMemcpyHostToDevice, s));
+    }
+    int32_t *d_status = nullptr;
+    int rc = ultra_chain_launch(ctx, n_inst, h_cnt.data(), ch.ioff.as<int64_t>(), nullptr, ch.x.as<int32_t>(), ch.y.as<int32_t>(),
+                                ch.c.as<int32_t>(), ch.d.as<int32_t>(), ch.val.as<double>(), solver, overlap_small, overlap_large,
+                                ch.idx.as<int32_t>(), ch.len.as<int32_t>(), ch.value.as<double>(), &d_status);
+    if (rc != ULTRA_OK) { (void)hipStreamSynchronize(s); return rc; }
     int32_t status = 0;
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(chain_len, ch.len.p, ni * 4, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(value, ch.value.p, ni * 8, hipMemcpyDeviceToHost, s));

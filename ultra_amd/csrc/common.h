@@ -36,6 +36,9 @@ struct MyersClass {
     int32_t max_t;      // longest target in the class
     int64_t lb, le;     // location (CSR) range, known after the forward pass
     int64_t hb, he;     // hit (ed >= 0) range
+    double cells;       // forward-pass cells of the class (sum of q_len * t_len)
+    float fwd_ms;       // device time of the class's forward launch in the last run
+    hipEvent_t ev0, ev1;
 };
 
 struct MyersState {
@@ -56,7 +59,21 @@ struct MyersState {
 };
 
 struct ChainState {
-    DevBuf off, x, y, c, d, val, idx, len, value, work;
+    DevBuf ioff, off, x, y, c, d, val, idx, len, value, work;
+    std::vector<int32_t> h_list;     // kept alive until the stream has consumed them
+    std::vector<int64_t> h_workoff;
+};
+
+struct MamState {
+    bool staged = false, ran = false;
+    int32_t n_cand = 0, n_inst = 0, max_cand = 0;
+    int64_t total_cap = 0, total_chain = 0, total_mam = 0;
+    float ms[3] = {0, 0, 0}; // MAM build, chaining, chain gather
+    std::vector<int64_t> h_instbase;
+    std::vector<int32_t> h_nmam;
+    DevBuf kind, estart, estop, pair, pairc, seqlen, seqid, candoff, readlen, fps, lps, cap, capoff, instbase, scantmp, flag,
+        mx, my, mc, md, mmsl, mcand, mval, nmam, chainidx, chainlen, value, lenw, chainoff, cx, cy, cc, cd, cmsl, ccand, cj, cval;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct ultra_ctx {
@@ -67,6 +84,7 @@ struct ultra_ctx {
     hipDeviceProp_t prop;
     MyersState my;
     ChainState ch;
+    MamState mam;
 };
 
 #define ULTRA_HIP_CHECK(ctx, call)                                                                      \
@@ -91,5 +109,12 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
                            const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                            const int32_t *k);
 int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops);
+int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, const int64_t *d_off, const int32_t *d_cnt,
+                       const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
+                       int32_t solver, int32_t overlap_small, int32_t overlap_large,
+                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out);
+// exclusive scan of n 64-bit values on ctx->stream (tmp: scratch, grown as needed)
+hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp);
 void ultra_myers_free(ultra_ctx *ctx);
 void ultra_chain_free(ultra_ctx *ctx);
+void ultra_mam_free(ultra_ctx *ctx);

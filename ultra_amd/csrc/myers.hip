@@ -540,32 +540,31 @@ int class_of(int m)
     return -1;
 }
 
-hipError_t device_scan(ultra_ctx *ctx, MyersState &st, int64_t n)
+} // namespace
+
+hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp)
 {
-    // three-kernel exclusive scan of st.packed -> st.scanned (n <= 2^20 * 1024)
+    // three-level exclusive scan (n <= 2^30)
+    if (n <= 0) return hipSuccess;
     int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     hipError_t e;
-    if ((e = st.blocksum.ensure(sizeof(uint64_t) * (size_t)(2 * nb + 2 * SCAN_BLOCK))) != hipSuccess) return e;
-    uint64_t *bs = st.blocksum.as<uint64_t>();
+    if ((e = tmp.ensure(sizeof(uint64_t) * (size_t)(2 * nb + 2 * SCAN_BLOCK + 2 * ((nb + SCAN_BLOCK - 1) / SCAN_BLOCK)))) != hipSuccess) return e;
+    uint64_t *bs = tmp.as<uint64_t>();
     uint64_t *bs2 = bs + nb;
-    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, st.packed.as<uint64_t>(),
-                       st.scanned.as<uint64_t>(), bs, n);
+    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, in, out, bs, n);
     if (nb > 1) {
         if (nb > (int64_t)SCAN_BLOCK * SCAN_BLOCK) return hipErrorInvalidValue;
         int64_t nb2 = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
         uint64_t *bs3 = bs2 + nb;
-        // scan of block sums (two levels are enough for n <= 2^30)
         hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ctx->stream, bs, bs2, bs3, nb);
         if (nb2 > 1) {
             hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, bs3, bs3 + nb2, (uint64_t *)nullptr, nb2);
             hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ctx->stream, bs2, bs3 + nb2, nb);
         }
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, st.scanned.as<uint64_t>(), bs2, n);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, out, bs2, n);
     }
     return hipGetLastError();
 }
-
-} // namespace
 
 void ultra_myers_free(ultra_ctx *ctx)
 {
@@ -575,6 +574,8 @@ void ultra_myers_free(ultra_ctx *ctx)
                       &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto &mc : st.classes) { if (mc.ev0) (void)hipEventDestroy(mc.ev0); if (mc.ev1) (void)hipEventDestroy(mc.ev1); }
+    st.classes.clear();
 }
 
 int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
@@ -622,6 +623,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
         if (cls[a] != cls[b]) return cls[a] < cls[b];
         return t_len[a] < t_len[b];
     });
+    for (auto &mc : st.classes) { if (mc.ev0) (void)hipEventDestroy(mc.ev0); if (mc.ev1) (void)hipEventDestroy(mc.ev1); }
     st.classes.clear();
     st.h_qoff.resize(n_pairs); st.h_toff.resize(n_pairs); st.h_qlen.resize(n_pairs); st.h_tlen.resize(n_pairs); st.h_k.resize(n_pairs);
     for (int32_t i = 0; i < n_pairs; i++) {
@@ -632,9 +634,11 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
         if (st.classes.empty() || st.classes.back().G != kClasses[c].G || st.classes.back().W != kClasses[c].W) {
             MyersClass mc; mc.G = kClasses[c].G; mc.W = kClasses[c].W; mc.pb = i; mc.pe = i; mc.max_t = 0;
             mc.lb = mc.le = mc.hb = mc.he = 0;
+            mc.cells = 0; mc.fwd_ms = 0; mc.ev0 = mc.ev1 = nullptr;
             st.classes.push_back(mc);
         }
         st.classes.back().pe = i + 1;
+        st.classes.back().cells += (double)q_len[p] * (double)t_len[p];
         st.classes.back().max_t = std::max(st.classes.back().max_t, t_len[p]);
     }
     st.n_pairs = n_pairs; st.N = (int64_t)enc.size(); st.S = S; st.cells = cells;
@@ -666,6 +670,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
     }
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // enc/h_* are host temporaries
     for (auto &e : st.ev) if (!e) ULTRA_HIP_CHECK(ctx, hipEventCreate(&e));
+    for (auto &mc : st.classes) { ULTRA_HIP_CHECK(ctx, hipEventCreate(&mc.ev0)); ULTRA_HIP_CHECK(ctx, hipEventCreate(&mc.ev1)); }
     st.staged = true;
     return ULTRA_OK;
 }
@@ -697,11 +702,13 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     for (auto &mc : st.classes) {
         a.begin = mc.pb; a.end = mc.pe;
         int cls = class_of(64 * mc.G * mc.W);
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev0, s));
         ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD>(ctx, cls, a, mc.pe - mc.pb, 0));
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev1, s));
     }
     // ---- CSR offsets ----
     hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n);
-    ULTRA_HIP_CHECK(ctx, device_scan(ctx, st, n));
+    ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, st.packed.as<uint64_t>(), st.scanned.as<uint64_t>(), n, st.blocksum));
     hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, s, st.scanned.as<uint64_t>(), st.packed.as<uint64_t>(),
                        st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), n);
     {
@@ -790,6 +797,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[1], st.ev[1], st.ev[2]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[2], st.ev[2], st.ev[3]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[3], st.ev[0], st.ev[3]));
+    for (auto &mc : st.classes) ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&mc.fwd_ms, mc.ev0, mc.ev1));
     st.ran = true;
     return ULTRA_OK;
 }

@@ -20,7 +20,8 @@ _ERR_NAMES = {-1: "ULTRA_E_ARG", -2: "ULTRA_E_HIP", -3: "ULTRA_E_CAPACITY", -4: 
 EXPORTS = [
     "ultra_cfg_default", "ultra_ctx_create", "ultra_ctx_destroy", "ultra_last_error", "ultra_device_count",
     "ultra_device_info", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
-    "ultra_myers_last_timing", "ultra_chain_mams_batch",
+    "ultra_myers_last_timing", "ultra_myers_class_timing", "ultra_chain_mams_batch",
+    "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
 ]
 
 
@@ -33,6 +34,29 @@ class UltraError(RuntimeError):
 class Cfg(C.Structure):
     _fields_ = [("chain_switch_n", C.c_int32), ("overlap_small", C.c_int32), ("overlap_large", C.c_int32),
                 ("loc_slots", C.c_int32)]
+
+
+_I32P, _I64P, _U8P, _F64P = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+
+
+class MamInput(C.Structure):
+    """ultra_mam_input (include/ultra_hip.h)."""
+    _fields_ = [("arena", _U8P), ("arena_len", C.c_size_t), ("n_pairs", C.c_int32),
+                ("q_off", _I64P), ("q_len", _I32P), ("t_off", _I64P), ("t_len", _I32P), ("k", _I32P),
+                ("n_cand", C.c_int32), ("cand_kind", _U8P), ("cand_e_start", _I32P), ("cand_e_stop", _I32P),
+                ("cand_pair", _I32P), ("cand_pair_contained", _I32P), ("cand_seq_len", _I32P), ("cand_seq_id", _I32P),
+                ("n_inst", C.c_int32), ("inst_cand_off", _I64P), ("inst_read_len", _I32P),
+                ("inst_first_part_stop", _I64P), ("inst_last_part_start", _I64P)]
+
+
+class MamOutput(C.Structure):
+    """ultra_mam_output (include/ultra_hip.h)."""
+    _fields_ = [("value", _F64P), ("n_mam", _I32P), ("chain_off", _I64P), ("chain_cap", C.c_int64),
+                ("chain_x", _I32P), ("chain_y", _I32P), ("chain_c", _I32P), ("chain_d", _I32P), ("chain_val", _F64P),
+                ("chain_msl", _I32P), ("chain_cand", _I32P), ("chain_j", _I32P),
+                ("mam_cap", C.c_int64), ("mam_off", _I64P),
+                ("mam_x", _I32P), ("mam_y", _I32P), ("mam_c", _I32P), ("mam_d", _I32P), ("mam_val", _F64P),
+                ("mam_msl", _I32P), ("mam_cand", _I32P)]
 
 
 _lib = None
@@ -63,8 +87,15 @@ def load():
     lib.ultra_myers_run.argtypes = [vp]
     lib.ultra_myers_fetch.argtypes = [vp, i32p, i32p, i64p, i32p, i32p, C.c_int64, i64p, i32p]
     lib.ultra_myers_last_timing.argtypes = [vp, f64p, C.POINTER(C.c_float)]
+    lib.ultra_myers_class_timing.argtypes = [vp, C.c_int32, i32p, i32p, f64p, C.POINTER(C.c_float), i32p]
     lib.ultra_chain_mams_batch.argtypes = [vp, C.c_int32, i64p, i32p, i32p, i32p, i32p, f64p, C.c_int32, C.c_int32,
                                            C.c_int32, i32p, i32p, f64p]
+    lib.ultra_mam_batch.argtypes = [vp, C.POINTER(MamInput), C.c_double, C.POINTER(MamOutput)]
+    lib.ultra_mam_stage.argtypes = [vp, C.POINTER(MamInput)]
+    lib.ultra_mam_run.argtypes = [vp, C.c_double]
+    lib.ultra_mam_sizes.argtypes = [vp, i64p, i64p]
+    lib.ultra_mam_fetch.argtypes = [vp, C.POINTER(MamOutput)]
+    lib.ultra_mam_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -178,6 +209,14 @@ class Context(object):
         self._check(self.lib.ultra_myers_last_timing(self._h, C.byref(cells), ms))
         return cells.value, [ms[i] for i in range(4)]
 
+    def myers_class_timing(self):
+        """{(G, W): (cells, forward_ms)} of the last run."""
+        cap = 32
+        G = (C.c_int32 * cap)(); W = (C.c_int32 * cap)(); cells = (C.c_double * cap)(); ms = (C.c_float * cap)()
+        n = C.c_int32()
+        self._check(self.lib.ultra_myers_class_timing(self._h, cap, G, W, cells, ms, C.byref(n)))
+        return {(G[i], W[i]): (cells[i], ms[i]) for i in range(min(n.value, cap))}
+
     def myers_fetch(self):
         n = self._staged_n
         ed = np.zeros(n, np.int32); nl = np.zeros(n, np.int32); fi = np.zeros(n, np.int32)
@@ -196,6 +235,65 @@ class Context(object):
             break
         return {"ed": ed, "n_loc": nl, "loc_off": lo, "loc_start": ls[:int(lo[-1])], "loc_end": le[:int(lo[-1])],
                 "first_ins": fi}
+
+    # ---- fused MAM stage -----------------------------------------------------------------------
+    def mam_stage(self, packed):
+        """packed: dict of numpy arrays named like the fields of ultra_mam_input (host -> HBM)."""
+        spec = [("arena", np.uint8, C.c_uint8), ("q_off", np.int64, C.c_int64), ("q_len", np.int32, C.c_int32),
+                ("t_off", np.int64, C.c_int64), ("t_len", np.int32, C.c_int32), ("k", np.int32, C.c_int32),
+                ("cand_kind", np.uint8, C.c_uint8), ("cand_e_start", np.int32, C.c_int32), ("cand_e_stop", np.int32, C.c_int32),
+                ("cand_pair", np.int32, C.c_int32), ("cand_pair_contained", np.int32, C.c_int32),
+                ("cand_seq_len", np.int32, C.c_int32), ("cand_seq_id", np.int32, C.c_int32),
+                ("inst_cand_off", np.int64, C.c_int64), ("inst_read_len", np.int32, C.c_int32),
+                ("inst_first_part_stop", np.int64, C.c_int64), ("inst_last_part_start", np.int64, C.c_int64)]
+        keep, inp = {}, MamInput()
+        for name, dt, ct in spec:
+            arr = _arr(packed[name], dt)
+            keep[name] = arr
+            setattr(inp, name, _ptr(arr, ct))
+        inp.arena_len = keep["arena"].size
+        inp.n_pairs = len(keep["k"])
+        inp.n_cand = len(keep["cand_kind"])
+        inp.n_inst = len(keep["inst_read_len"])
+        self._mam_n_inst = inp.n_inst
+        self._check(self.lib.ultra_mam_stage(self._h, C.byref(inp)))
+
+    def mam_run(self, min_acc):
+        self._check(self.lib.ultra_mam_run(self._h, float(min_acc)))
+
+    def mam_timing(self):
+        ms = (C.c_float * 3)()
+        self._check(self.lib.ultra_mam_last_timing(self._h, ms))
+        return [ms[i] for i in range(3)]
+
+    def mam_fetch(self, want_all=False):
+        """Results of the last mam_run as numpy arrays (chains, and optionally the full MAM lists)."""
+        ni = self._mam_n_inst
+        nc, nm = C.c_int64(), C.c_int64()
+        self._check(self.lib.ultra_mam_sizes(self._h, C.byref(nc), C.byref(nm)))
+        tc, tm = max(int(nc.value), 1), max(int(nm.value), 1)
+        r = {"value": np.zeros(max(ni, 1), np.float64), "n_mam": np.zeros(max(ni, 1), np.int32),
+             "chain_off": np.zeros(ni + 1, np.int64)}
+        for f in ("x", "y", "c", "d", "msl", "cand", "j"):
+            r["chain_" + f] = np.zeros(tc, np.int32)
+        r["chain_val"] = np.zeros(tc, np.float64)
+        out = MamOutput()
+        out.value, out.n_mam, out.chain_off = _ptr(r["value"], C.c_double), _ptr(r["n_mam"], C.c_int32), _ptr(r["chain_off"], C.c_int64)
+        out.chain_cap = tc
+        for f in ("x", "y", "c", "d", "msl", "cand", "j"):
+            setattr(out, "chain_" + f, _ptr(r["chain_" + f], C.c_int32))
+        out.chain_val = _ptr(r["chain_val"], C.c_double)
+        if want_all:
+            r["mam_off"] = np.zeros(ni + 1, np.int64)
+            out.mam_off, out.mam_cap = _ptr(r["mam_off"], C.c_int64), tm
+            for f in ("x", "y", "c", "d", "msl", "cand"):
+                r["mam_" + f] = np.zeros(tm, np.int32)
+                setattr(out, "mam_" + f, _ptr(r["mam_" + f], C.c_int32))
+            r["mam_val"] = np.zeros(tm, np.float64)
+            out.mam_val = _ptr(r["mam_val"], C.c_double)
+        self._check(self.lib.ultra_mam_fetch(self._h, C.byref(out)))
+        r["value"], r["n_mam"] = r["value"][:ni], r["n_mam"][:ni]
+        return r
 
     # ---- chaining ----------------------------------------------------------------------------
     def chain_mams_batch(self, inst_off, x, y, c, d, val, solver=0, overlap_small=-1, overlap_large=-1):
