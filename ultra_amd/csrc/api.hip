@@ -37,6 +37,11 @@ int ultra_ctx_create(int device, const ultra_cfg *cfg, ultra_ctx **out)
     // the code object is built for gfx950 only; refuse anything else loudly
     if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return ULTRA_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ULTRA_E_HIP; }
+    bool ok = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < kAuxStreams && ok; i++)
+        ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ultra_ctx_destroy(ctx); return ULTRA_E_HIP; }
     *out = ctx;
     return ULTRA_OK;
 }
@@ -49,6 +54,11 @@ void ultra_ctx_destroy(ultra_ctx *ctx)
     ultra_myers_free(ctx);
     ultra_chain_free(ctx);
     ultra_mam_free(ctx);
+    for (int i = 0; i < kAuxStreams; i++) {
+        if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
+        if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -76,9 +76,15 @@ struct MamState {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
+constexpr int kAuxStreams = 4;
+
 struct ultra_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // size classes of one pass are independent: they are launched round-robin on these streams so
+    // that short launches overlap (fork = aux streams wait for `stream`, join = `stream` waits for them)
+    hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
     ultra_cfg cfg;
     std::string err;
     hipDeviceProp_t prop;
@@ -98,6 +104,22 @@ struct ultra_ctx {
             return ULTRA_E_HIP;                                                                         \
         }                                                                                               \
     } while (0)
+
+static inline hipError_t ultra_fork(ultra_ctx *ctx)
+{
+    hipError_t e = hipEventRecord(ctx->fork_ev, ctx->stream);
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; i++) e = hipStreamWaitEvent(ctx->aux[i], ctx->fork_ev, 0);
+    return e;
+}
+static inline hipError_t ultra_join(ultra_ctx *ctx)
+{
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; i++) {
+        e = hipEventRecord(ctx->join_ev[i], ctx->aux[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->join_ev[i], 0);
+    }
+    return e;
+}
 
 static inline int ultra_fail(ultra_ctx *ctx, int code, const std::string &msg)
 {

@@ -32,7 +32,7 @@ struct MyArgs {
     int32_t *ed; int32_t *nloc; int32_t *slots; int slot_cap;
     const int64_t *loc_off; int32_t *loc_end; int32_t *loc_start; const int32_t *loc_pair;
     const int32_t *hit_pairs; int32_t *first_ins;
-    uint64_t *trP, *trM; int32_t *trS; int64_t region; // trace scratch, entries per wave (lane kernels) / per pair slot (group kernels)
+    ulonglong2 *tr; int64_t region; // trace scratch {Pv, Ph} per word and column; entries per wave (lane kernels) / per pair slot (group kernels)
     int32_t Lmax;
     uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
     int64_t begin, end;
@@ -94,7 +94,7 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p)
 
 // One 64-row word, one column (Hyyro 2003 formulation of Myers 1999).  hp/hm = horizontal
 // carry into the word's top row (+1 / -1), updated to the carry out of its bottom row.
-__device__ __forceinline__ void word_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t &hp, uint32_t &hm)
+__device__ __forceinline__ void word_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t &hp, uint32_t &hm, uint64_t &Ph0)
 {
     uint64_t Xv = Eq | Mv;
     Eq |= (uint64_t)hm;
@@ -103,6 +103,7 @@ __device__ __forceinline__ void word_step(uint64_t &Pv, uint64_t &Mv, uint64_t E
     uint64_t Ph = (u & Mv) | ~u; // = Mv | ~(Xh | Pv)
     uint64_t Mh = Pv & Xh;
     uint32_t hpo = (uint32_t)(Ph >> 63), hmo = (uint32_t)(Mh >> 63);
+    Ph0 = Ph; // bit i: D[i][j] - D[i][j-1] == +1
     Ph = (Ph << 1) | (uint64_t)hp;
     Mh = (Mh << 1) | (uint64_t)hm;
     uint64_t w = Xv | Ph;
@@ -126,51 +127,38 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return v;
 }
 
-// Traceback helpers: column-major store of (Pv, Mv, bottom score) per word; stride = distance between
-// consecutive words of one pair, colstride = distance between columns.
-struct TraceView {
-    const uint64_t *P, *M; const int32_t *S;
-    int64_t stride, colstride;
-    int pad;
-    __device__ __forceinline__ int cell(int ip, int c) const
-    {
-        int64_t o = (int64_t)c * colstride + (int64_t)(ip >> 6) * stride;
-        uint64_t p = P[o], m = M[o];
-        int pos = ip & 63;
-        p = (p >> pos) >> 1; m = (m >> pos) >> 1;
-        return S[o] - (__popcll(p) - __popcll(m));
-    }
-    // value at padded row ip (-1 = above everything), column c (-1 = left boundary)
-    __device__ __forceinline__ int D(int ip, int c) const
-    {
-        if (c < 0) { int v = ip - pad + 1; return v > 0 ? v : 0; }
-        if (ip < 0) return c + 1;
-        return cell(ip, c);
-    }
-};
-
-// Walks the first location's path from the bottom-right cell; tie rule: up (I), left (D), diagonal.
-__device__ __forceinline__ void traceback(const TraceView &tv, int rows, int L, int best,
-                                          uint8_t *ops, int ops_cap, int &n_ins, int &n_ops)
+// Traceback of the first location over the stored NW columns.  Per word and column the pass keeps
+// Pv (bit i: D[i][c] - D[i-1][c] == +1, "up" is an optimal predecessor) and Ph (bit i:
+// D[i][c] - D[i][c-1] == +1, "left" is one); neither bit set means the diagonal.  Tie rule of the
+// walk from the bottom-right cell: up (I), then left (D), then diagonal - so one 16-byte load per
+// step decides it.  stride = distance between consecutive words of one column, colstride = between
+// columns.  Rows above `pad` are top padding: once the query is used up only deletions remain; once
+// the target is used up only insertions remain.
+__device__ __forceinline__ void traceback(const ulonglong2 *tr, int64_t stride, int64_t colstride, int pad, int rows, int L,
+                                          const uint8_t *q, const uint8_t *t, uint8_t *ops, int ops_cap, int &n_ins, int &n_ops)
 {
     int ip = rows - 1, c = L - 1;
     int ins = 0, cnt = 0;
-    int cur = best;
-    while (ip >= tv.pad || c >= 0) {
-        int up = tv.D(ip - 1, c);
+    int cw = -1, cc = -1;
+    ulonglong2 e = {0, 0};
+    while (ip >= pad && c >= 0) {
+        const int w = ip >> 6;
+        if (w != cw || c != cc) { e = tr[(int64_t)c * colstride + (int64_t)w * stride]; cw = w; cc = c; }
+        const uint64_t bit = ((uint64_t)1) << (ip & 63);
         int code;
-        if (ip >= tv.pad && up + 1 == cur) { code = 1; ins++; ip--; cur = up; }
-        else {
-            int left = tv.D(ip, c - 1);
-            if (c >= 0 && left + 1 == cur) { code = 2; c--; cur = left; }
-            else {
-                int ul = tv.D(ip - 1, c - 1);
-                code = (ul == cur) ? 0 : 3;
-                ip--; c--; cur = ul;
-            }
-        }
+        if (e.x & bit) { code = 1; ins++; ip--; }
+        else if (e.y & bit) { code = 2; c--; }
+        else { code = (ops && q[ip - pad] != t[c]) ? 3 : 0; ip--; c--; }
         if (ops && cnt < ops_cap) ops[cnt] = (uint8_t)code;
         cnt++;
+    }
+    if (ip >= pad) { // left boundary reached: the remaining query bases are insertions
+        const int r = ip - pad + 1;
+        if (ops) for (int u = 0; u < r; u++) if (cnt + u < ops_cap) ops[cnt + u] = 1;
+        ins += r; cnt += r;
+    } else if (c >= 0) { // query used up: the remaining target bases are deletions
+        if (ops) for (int u = 0; u <= c; u++) if (cnt + u < ops_cap) ops[cnt + u] = 2;
+        cnt += c + 1;
     }
     n_ins = ins; n_ops = cnt;
 }
@@ -218,22 +206,16 @@ __global__ void __launch_bounds__(256) myers_lane(MyArgs a)
             }
         }
         uint64_t Pv[W], Mv[W];
-        int32_t sc[W];
 #pragma unroll
-        for (int b = 0; b < W; b++) {
-            Pv[b] = ~pad_mask(pad, b); Mv[b] = 0;
-            int v = 64 * (b + 1) - pad; sc[b] = v > 0 ? v : 0;
-        }
+        for (int b = 0; b < W; b++) { Pv[b] = ~pad_mask(pad, b); Mv[b] = 0; }
         const uint32_t top_hp = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? 0u : 1u;
         int32_t score = it.m;
         int32_t best = 0x3fffffff, cnt = 0, lim = it.k, last = -1;
         int32_t *out = nullptr; int32_t out_cap = 0;
         if (MODE == MODE_FWD) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
         if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
-        uint64_t *tP = nullptr, *tM = nullptr; int32_t *tS = nullptr;
-        if (MODE == MODE_NW) {
-            tP = a.trP + gwave * a.region + lane; tM = a.trM + gwave * a.region + lane; tS = a.trS + gwave * a.region + lane;
-        }
+        ulonglong2 *tT = nullptr;
+        if (MODE == MODE_NW) tT = a.tr + gwave * a.region + lane;
         const int n = it.valid ? it.n : 0;
         const int nmax = wave_max_i32(n);
         uint64_t tw = 0, tnext = (n > 0) ? load8(it.t) : 0;
@@ -248,11 +230,11 @@ __global__ void __launch_bounds__(256) myers_lane(MyArgs a)
                 uint32_t hp = top_hp, hm = 0;
 #pragma unroll
                 for (int b = 0; b < W; b++) {
-                    word_step(Pv[b], Mv[b], pe[b * 64], hp, hm);
+                    uint64_t ph0;
+                    word_step(Pv[b], Mv[b], pe[b * 64], hp, hm, ph0);
                     if (MODE == MODE_NW) {
-                        sc[b] += (int32_t)hp - (int32_t)hm;
-                        int64_t o = ((int64_t)j * W + b) * 64;
-                        tP[o] = Pv[b]; tM[o] = Mv[b]; tS[o] = sc[b];
+                        ulonglong2 e; e.x = Pv[b]; e.y = ph0;
+                        tT[((int64_t)j * W + b) * 64] = e;
                     }
                 }
                 score += (int32_t)hp - (int32_t)hm;
@@ -275,11 +257,10 @@ __global__ void __launch_bounds__(256) myers_lane(MyArgs a)
         } else if (MODE == MODE_NW) {
             __threadfence();
             if (it.valid) {
-                TraceView tv{tP, tM, tS, 64, (int64_t)W * 64, pad};
                 uint8_t *ops = nullptr; int ops_cap = 0;
                 if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
                 int ins, nops;
-                traceback(tv, ROWS, it.n, it.best, ops, ops_cap, ins, nops);
+                traceback(tT, 64, (int64_t)W * 64, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops);
                 a.first_ins[it.pair] = ins;
                 if (a.n_ops) a.n_ops[it.pair] = nops;
             }
@@ -311,7 +292,6 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
         const int pad = ROWS - it.m;
         const uint64_t padfill_on = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ~(uint64_t)0 : 0;
         uint64_t Pv[W], Mv[W];
-        int32_t sc[W];
 #pragma unroll
         for (int w = 0; w < W; w++) {
             const int blk = g * W + w;
@@ -323,7 +303,6 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
                 }
             }
             Pv[w] = ~pad_mask(pad, blk); Mv[w] = 0;
-            int v = 64 * (blk + 1) - pad; sc[w] = v > 0 ? v : 0;
         }
         const uint32_t top_hp = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? 0u : 1u;
         int32_t score = it.m;
@@ -331,11 +310,8 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
         int32_t *out = nullptr; int32_t out_cap = 0;
         if (MODE == MODE_FWD) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
         if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
-        uint64_t *tP = nullptr, *tM = nullptr; int32_t *tS = nullptr;
-        if (MODE == MODE_NW) {
-            int64_t slot = (int64_t)blockIdx.x * P + p;
-            tP = a.trP + slot * a.region; tM = a.trM + slot * a.region; tS = a.trS + slot * a.region;
-        }
+        ulonglong2 *tT = nullptr;
+        if (MODE == MODE_NW) tT = a.tr + ((int64_t)blockIdx.x * P + p) * a.region;
         const int n = it.valid ? it.n : 0;
         const int nmax = wave_max_i32(n);
         const int steps = nmax + G - 1;
@@ -349,11 +325,11 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
                 const uint64_t *pe = peq + (size_t)code * NB + g * W;
 #pragma unroll
                 for (int w = 0; w < W; w++) {
-                    word_step(Pv[w], Mv[w], pe[w], hp, hm);
+                    uint64_t ph0;
+                    word_step(Pv[w], Mv[w], pe[w], hp, hm, ph0);
                     if (MODE == MODE_NW) {
-                        sc[w] += (int32_t)hp - (int32_t)hm;
-                        int64_t o = (int64_t)col * NB + g * W + w;
-                        tP[o] = Pv[w]; tM[o] = Mv[w]; tS[o] = sc[w];
+                        ulonglong2 e; e.x = Pv[w]; e.y = ph0;
+                        tT[(int64_t)col * NB + g * W + w] = e;
                     }
                 }
                 hp_out = hp; hm_out = hm;
@@ -378,11 +354,10 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
         } else if (MODE == MODE_NW) {
             __threadfence();
             if (it.valid && g == 0) {
-                TraceView tv{tP, tM, tS, 1, (int64_t)NB, pad};
                 uint8_t *ops = nullptr; int ops_cap = 0;
                 if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
                 int ins, nops;
-                traceback(tv, ROWS, it.n, it.best, ops, ops_cap, ins, nops);
+                traceback(tT, 1, (int64_t)NB, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops);
                 a.first_ins[it.pair] = ins;
                 if (a.n_ops) a.n_ops[it.pair] = nops;
             }
@@ -479,7 +454,7 @@ constexpr int kMaxQuery = 64 * 64 * 8;
 constexpr int kMaxSymbols = 16;
 constexpr size_t kArenaPad = 64;
 
-template <int W, int MODE> hipError_t launch_lane(ultra_ctx *ctx, const MyArgs &a, int64_t items, int max_waves)
+template <int W, int MODE> hipError_t launch_lane(hipStream_t stream, const MyArgs &a, int64_t items, int max_waves)
 {
     int S = a.S;
     size_t per_wave = (size_t)S * W * 64 * sizeof(uint64_t);
@@ -493,11 +468,11 @@ template <int W, int MODE> hipError_t launch_lane(ultra_ctx *ctx, const MyArgs &
     if (max_waves > 0 && waves > max_waves) waves = max_waves;
     int64_t blocks = (waves + wpb - 1) / wpb;
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL((myers_lane<W, MODE>), dim3((unsigned)blocks), dim3(64 * wpb), shmem, ctx->stream, a);
+    hipLaunchKernelGGL((myers_lane<W, MODE>), dim3((unsigned)blocks), dim3(64 * wpb), shmem, stream, a);
     return hipGetLastError();
 }
 
-template <int G, int W, int MODE> hipError_t launch_group(ultra_ctx *ctx, const MyArgs &a, int64_t items, int max_blocks)
+template <int G, int W, int MODE> hipError_t launch_group(hipStream_t stream, const MyArgs &a, int64_t items, int max_blocks)
 {
     constexpr int P = 64 / G;
     size_t shmem = (size_t)P * a.S * G * W * sizeof(uint64_t);
@@ -508,11 +483,11 @@ template <int G, int W, int MODE> hipError_t launch_group(ultra_ctx *ctx, const 
     int64_t blocks = (items + P - 1) / P;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL((myers_group<G, W, MODE>), dim3((unsigned)blocks), dim3(64), shmem, ctx->stream, a);
+    hipLaunchKernelGGL((myers_group<G, W, MODE>), dim3((unsigned)blocks), dim3(64), shmem, stream, a);
     return hipGetLastError();
 }
 
-template <int MODE> hipError_t launch_class(ultra_ctx *ctx, int cls, const MyArgs &a, int64_t items, int max_par)
+template <int MODE> hipError_t launch_class(hipStream_t ctx, int cls, const MyArgs &a, int64_t items, int max_par)
 {
     switch (cls) {
     case 0: return launch_lane<1, MODE>(ctx, a, items, max_par);
@@ -699,13 +674,21 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.nops.p, 0, (size_t)n * 4, s));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[0], s));
     // ---- pass 1: forward HW ----
-    for (auto &mc : st.classes) {
-        a.begin = mc.pb; a.end = mc.pe;
-        int cls = class_of(64 * mc.G * mc.W);
-        ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev0, s));
-        ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD>(ctx, cls, a, mc.pe - mc.pb, 0));
-        ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev1, s));
+    ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    {
+        // longest-running classes first
+        int q = 0;
+        for (auto it = st.classes.rbegin(); it != st.classes.rend(); ++it, ++q) {
+            auto &mc = *it;
+            hipStream_t cs = ctx->aux[q % kAuxStreams];
+            a.begin = mc.pb; a.end = mc.pe;
+            int cls = class_of(64 * mc.G * mc.W);
+            ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev0, cs));
+            ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD>(cs, cls, a, mc.pe - mc.pb, 0));
+            ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev1, cs));
+        }
     }
+    ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     // ---- CSR offsets ----
     hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n);
     ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, st.packed.as<uint64_t>(), st.scanned.as<uint64_t>(), n, st.blocksum));
@@ -737,28 +720,41 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
                        st.hitoff.as<int64_t>(), a.loc_end, st.locpair.as<int32_t>(), st.hitpairs.as<int32_t>(), n);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots ----
-    for (auto &mc : st.classes) {
-        a.begin = mc.pb; a.end = mc.pe;
-        int cls = class_of(64 * mc.G * mc.W);
-        ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD_EXACT>(ctx, cls, a, mc.pe - mc.pb, 0));
+    ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    {
+        int q = 0;
+        for (auto it = st.classes.rbegin(); it != st.classes.rend(); ++it, ++q) {
+            auto &mc = *it;
+            a.begin = mc.pb; a.end = mc.pe;
+            int cls = class_of(64 * mc.G * mc.W);
+            ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD_EXACT>(ctx->aux[q % kAuxStreams], cls, a, mc.pe - mc.pb, 0));
+        }
     }
+    ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     // ---- pass 2: start positions ----
-    for (auto &mc : st.classes) {
-        if (mc.le <= mc.lb) continue;
-        a.begin = mc.lb; a.end = mc.le;
-        int cls = class_of(64 * mc.G * mc.W);
-        ULTRA_HIP_CHECK(ctx, launch_class<MODE_REV>(ctx, cls, a, mc.le - mc.lb, 0));
+    ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    {
+        int q = 0;
+        for (auto it = st.classes.rbegin(); it != st.classes.rend(); ++it, ++q) {
+            auto &mc = *it;
+            if (mc.le <= mc.lb) continue;
+            a.begin = mc.lb; a.end = mc.le;
+            int cls = class_of(64 * mc.G * mc.W);
+            ULTRA_HIP_CHECK(ctx, launch_class<MODE_REV>(ctx->aux[q % kAuxStreams], cls, a, mc.le - mc.lb, 0));
+        }
     }
+    ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
     // ---- pass 3: first-location traceback ----
     a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
     a.ops_off = want_ops ? st.opsoff.as<int64_t>() : nullptr;
-    const size_t budget = (size_t)6 << 30; // trace scratch budget (bytes)
+    const size_t budget = (size_t)16 << 30; // trace scratch budget (bytes)
     for (auto &mc : st.classes) {
         if (mc.he <= mc.hb) continue;
         int cls = class_of(64 * mc.G * mc.W);
         const int NB = mc.G * mc.W;
+        // first location: L = end - start + 1 <= m + ed <= m + k, and k <= m (clamped in setup_item)
         int64_t Lmax = std::min<int64_t>(mc.max_t, (int64_t)2 * 64 * NB);
         int64_t items = mc.he - mc.hb;
         int64_t region, units; // entries per unit (wave for lane kernels, pair slot for group kernels)
@@ -766,28 +762,26 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         if (mc.G == 1) {
             region = Lmax * mc.W * 64;
             int64_t waves = (items + 63) / 64;
-            units = std::min<int64_t>(waves, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 20))));
+            units = std::min<int64_t>(waves, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 16))));
             units = std::min<int64_t>(units, (int64_t)ctx->prop.multiProcessorCount * 16);
             max_par = (int)units;
         } else {
             const int P = 64 / mc.G;
             region = Lmax * NB;
             int64_t blocks = (items + P - 1) / P;
-            int64_t b = std::min<int64_t>(blocks, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 20 * P))));
-            b = std::min<int64_t>(b, (int64_t)ctx->prop.multiProcessorCount * 8);
+            int64_t b = std::min<int64_t>(blocks, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 16 * P))));
+            b = std::min<int64_t>(b, (int64_t)ctx->prop.multiProcessorCount * 32);
             max_par = (int)b;
             units = b * P;
         }
         size_t entries = (size_t)region * (size_t)units;
         // lane kernels round the grid up to whole blocks: leave room for up to 3 extra waves
         size_t slack = (mc.G == 1) ? (size_t)region * 4 : 0;
-        ULTRA_HIP_CHECK(ctx, st.trace.ensure((entries + slack) * 20 + 64));
-        a.trP = st.trace.as<uint64_t>();
-        a.trM = a.trP + (entries + slack);
-        a.trS = (int32_t *)(a.trM + (entries + slack));
+        ULTRA_HIP_CHECK(ctx, st.trace.ensure((entries + slack) * 16 + 64));
+        a.tr = st.trace.as<ulonglong2>();
         a.region = region; a.Lmax = (int32_t)Lmax;
         a.begin = mc.hb; a.end = mc.he;
-        ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx, cls, a, items, max_par));
+        ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(s, cls, a, items, max_par));
         // the scratch buffer may be re-sized by the next class: wait before reuse
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
     }
