@@ -105,3 +105,27 @@ def test_round_trip_property_at_scale(ctx):
             # global distance of q vs t[s..e] equals ed: HW on the exact window cannot do better,
             # and the window achieves it only if both ends are used
             assert r["editDistance"] <= got["ed"][p]
+
+
+def test_banded_and_full_height_traceback_agree(ctx):
+    """The banded traceback (default) and the full-height one (cfg banded_traceback=0, also the
+    fallback for distances > 254) give the same insertion counts; both equal the oracle."""
+    from ultra_amd import lib
+    rng = np.random.RandomState(11)
+    full = lib.Context(0, cfg={"banded_traceback": 0})
+    try:
+        for qr, tr, n, rates in [((9, 300), (100, 900), 1500, (0.0, 0.05, 0.2, 0.35)),
+                                 ((300, 1400), (400, 2000), 200, (0.02, 0.1, 0.2)),
+                                 ((700, 1600), (900, 2400), 60, (0.3, 0.36))]:   # distances beyond every band class
+            pairs = helpers.make_pairs(rng, n, qr, tr, kmode="ref", planted=0.9, rates=rates)
+            a = _check(ctx, pairs)
+            b = _check(full, pairs)
+            assert np.array_equal(a["first_ins"], b["first_ins"])
+            assert (a["ed"] > 254).any() or qr[0] < 700
+    finally:
+        full.close()
+
+
+def test_banded_traceback_wide_alphabet(ctx):
+    rng = np.random.RandomState(12)
+    _check(ctx, helpers.make_pairs(rng, 600, (9, 400), (100, 900), kmode="ref", planted=0.9, alpha="ACGTNRYKMSWacg"))

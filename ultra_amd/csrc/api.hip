@@ -13,6 +13,7 @@ void ultra_cfg_default(ultra_cfg *cfg)
     cfg->overlap_small = 20;   // classify_read_with_mams.py:575
     cfg->overlap_large = 5;    // classify_read_with_mams.py:563
     cfg->loc_slots = 8;
+    cfg->banded_traceback = 1;
 }
 
 int ultra_device_count(void)

@@ -23,6 +23,7 @@
 namespace {
 
 enum { MODE_FWD = 0, MODE_FWD_EXACT = 1, MODE_REV = 2, MODE_NW = 3 };
+enum { kBandClasses = 4, kBandFallback = 4 }; // banded traceback: WB = 1, 2, 4, 8 words; class 4 = not banded
 
 struct MyArgs {
     const uint8_t *seq, *rseq;
@@ -32,6 +33,7 @@ struct MyArgs {
     int32_t *ed; int32_t *nloc; int32_t *slots; int slot_cap;
     const int64_t *loc_off; int32_t *loc_end; int32_t *loc_start; const int32_t *loc_pair;
     const int32_t *hit_pairs; int32_t *first_ins;
+    const uint8_t *band_cls; // per hit: band class, or nullptr when the banded traceback is off
     ulonglong2 *tr; int64_t region; // trace scratch {Pv, Ph} per word and column; entries per wave (lane kernels) / per pair slot (group kernels)
     int32_t Lmax;
     uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
@@ -72,6 +74,7 @@ template <int MODE> __device__ __forceinline__ Item setup_item(const MyArgs &a, 
         it.t = a.rseq + (a.N - a.t_off[p] - (int64_t)(e + 1));
     } else {
         int32_t p = a.hit_pairs[item];
+        if (a.band_cls && a.band_cls[item] != kBandFallback) it.valid = false; // handled by the banded kernel
         int64_t lo = a.loc_off[p];
         int32_t s = a.loc_start[lo], e = a.loc_end[lo];
         it.pair = p;
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(256) myers_lane(MyArgs a)
 
     for (int64_t base = a.begin + gwave * 64; base < a.end; base += nwaves * 64) {
         Item it = setup_item<MODE>(a, base + lane);
-        if (MODE == MODE_FWD_EXACT) {
+        if (MODE == MODE_FWD_EXACT || MODE == MODE_NW) {
             if (!__any(it.valid)) continue;
         }
         const int pad = ROWS - it.m;
@@ -286,7 +289,7 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
 
     for (int64_t base = a.begin + (int64_t)blockIdx.x * P; base < a.end; base += (int64_t)gridDim.x * P) {
         Item it = setup_item<MODE>(a, base + p);
-        if (MODE == MODE_FWD_EXACT) {
+        if (MODE == MODE_FWD_EXACT || MODE == MODE_NW) {
             if (!__any(it.valid)) continue;
         }
         const int pad = ROWS - it.m;
@@ -363,6 +366,163 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
             }
             __threadfence();
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// banded traceback kernel: lane-per-pair, diagonal band of 64*WB rows
+// ------------------------------------------------------------------------------------------------
+// The first location's global alignment has a KNOWN distance ed (forward + reverse passes), so every
+// cell of an optimal path lies within |row - column| <= ed of the main diagonal.  The window of
+// 64*WB rows slides down one row per column (Hyyro's diagonal formulation: the new vertical deltas
+// take D0 >> 1), which makes the cost per column independent of the query length, and the stored
+// traceback state {Pv, Ph} is WB words per column instead of ceil(m/64).  No Peq table: the window's
+// match vector is rebuilt from NP bit-planes of the query codes that slide with the window.
+// Window of column c: bit b <-> query row c - TOP + b, TOP = 32*WB - 1; needs ed <= 32*WB - 2.
+template <int WB, int NP>
+__global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items, int64_t n_items)
+{
+    constexpr int TOP = 32 * WB - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int64_t gwave = (int64_t)blockIdx.x * wpb + wave, nwaves = (int64_t)gridDim.x * wpb;
+    ulonglong2 *T = a.tr + gwave * a.region + lane; // entry (column c, word w) at T[(c * WB + w) * 64]
+    for (int64_t base = gwave * 64; base < n_items; base += nwaves * 64) {
+        const bool valid = base + lane < n_items;
+        int p = 0, m = 0, L = 0;
+        const uint8_t *q = a.seq, *t = a.seq;
+        if (valid) {
+            p = items[base + lane];
+            m = a.q_len[p];
+            const int64_t lo = a.loc_off[p];
+            const int s0 = a.loc_start[lo];
+            L = a.loc_end[lo] - s0 + 1;
+            q = a.seq + a.q_off[p];
+            t = a.seq + a.t_off[p] + s0;
+        }
+        uint64_t PL[NP][WB];
+#pragma unroll
+        for (int k = 0; k < NP; k++)
+#pragma unroll
+            for (int w = 0; w < WB; w++) PL[k][w] = 0;
+        uint64_t qw = 0;
+        int ri = 0; // next query row to enter the window
+        auto insert_row = [&]() {
+            if ((ri & 7) == 0) qw = ri < m ? load8(q + ri) : 0;
+            const uint32_t code1 = ri < m ? (uint32_t)(qw & 0xff) + 1u : 0u; // 0 = outside the query: matches nothing
+            qw >>= 8;
+            ri++;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+#pragma unroll
+                for (int w = 0; w < WB - 1; w++) PL[k][w] = (PL[k][w] >> 1) | (PL[k][w + 1] << 63);
+                PL[k][WB - 1] = (PL[k][WB - 1] >> 1) | ((uint64_t)((code1 >> k) & 1u) << 63);
+            }
+        };
+        for (int i = 0; i <= TOP; i++) insert_row(); // rows 0 .. TOP: the window of column -1
+        // column -1: D[r][-1] = r + 1 for query rows, 0 for the virtual rows above row 0
+        uint64_t VP[WB], VN[WB];
+#pragma unroll
+        for (int w = 0; w < WB; w++) {
+            // bit b <-> row -1 - TOP + b >= 0  <=>  b >= TOP + 1 = 32*WB
+            VP[w] = (64 * w >= TOP + 1) ? ~(uint64_t)0 : (64 * (w + 1) <= TOP + 1 ? 0 : (~(uint64_t)0) << ((TOP + 1) & 63));
+            VN[w] = 0;
+        }
+        const int Lmax = wave_max_i32(L);
+        uint64_t tw = 0;
+        for (int c = 0; c < Lmax; c++) {
+            if ((c & 7) == 0) tw = c < L ? load8(t + c) : 0;
+            const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
+            tw >>= 8;
+            uint64_t Eq[WB];
+#pragma unroll
+            for (int w = 0; w < WB; w++) Eq[w] = ~(uint64_t)0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const uint64_t mk = ((tc1 >> k) & 1u) ? 0 : ~(uint64_t)0;
+#pragma unroll
+                for (int w = 0; w < WB; w++) Eq[w] &= PL[k][w] ^ mk;
+            }
+            uint64_t D0[WB], HP[WB], HN[WB];
+            uint64_t carry = 0;
+#pragma unroll
+            for (int w = 0; w < WB; w++) {
+                const uint64_t x = Eq[w] & VP[w];
+                const uint64_t s1 = x + VP[w];
+                const uint64_t s2 = s1 + carry;
+                carry = (uint64_t)((s1 < x) | (s2 < s1));
+                D0[w] = (s2 ^ VP[w]) | Eq[w] | VN[w];
+                HP[w] = VN[w] | ~(D0[w] | VP[w]);
+                HN[w] = D0[w] & VP[w];
+            }
+#pragma unroll
+            for (int w = 0; w < WB; w++) {
+                const uint64_t X = (D0[w] >> 1) | (w + 1 < WB ? (D0[w + 1] << 63) : 0);
+                const uint64_t hps = (HP[w] >> 1) | (w + 1 < WB ? (HP[w + 1] << 63) : 0); // Ph in this column's alignment
+                VN[w] = X & HP[w];
+                VP[w] = HN[w] | ~(X | HP[w]);
+                if (c < L) { ulonglong2 e; e.x = VP[w]; e.y = hps; T[((int64_t)c * WB + w) * 64] = e; }
+            }
+            insert_row();
+        }
+        __threadfence();
+        if (valid) {
+            int r = m - 1, c = L - 1, ins = 0, cw = -1, cc = -1;
+            ulonglong2 e = {0, 0};
+            while (r >= 0 && c >= 0) {
+                const int b = r - c + TOP;
+                const int w = b >> 6;
+                if (w != cw || c != cc) { e = T[((int64_t)c * WB + w) * 64]; cw = w; cc = c; }
+                const uint64_t bit = ((uint64_t)1) << (b & 63);
+                if (e.x & bit) { ins++; r--; }
+                else if (e.y & bit) c--;
+                else { r--; c--; }
+            }
+            if (r >= 0) ins += r + 1;
+            a.first_ins[p] = ins;
+        }
+        __threadfence();
+    }
+}
+
+
+// class of every hit by its distance (band rows needed: 2*ed + 3) + per-class longest first location
+__global__ void __launch_bounds__(256) k_band_classify(MyArgs a, int64_t n_hits, int allow, uint8_t *cls, int32_t *max_l)
+{
+    __shared__ int32_t sh[kBandClasses + 1];
+    if (threadIdx.x <= kBandClasses) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_hits) {
+        const int32_t p = a.hit_pairs[i];
+        const int ed = a.ed[p];
+        const int64_t lo = a.loc_off[p];
+        const int L = a.loc_end[lo] - a.loc_start[lo] + 1;
+        int c = ed <= 30 ? 0 : ed <= 62 ? 1 : ed <= 126 ? 2 : ed <= 254 ? 3 : kBandFallback;
+        if (!allow) c = kBandFallback;
+        cls[i] = (uint8_t)c;
+        atomicMax(&sh[c], L);
+    }
+    __syncthreads();
+    if (threadIdx.x <= kBandClasses && sh[threadIdx.x] > 0) atomicMax(&max_l[threadIdx.x], sh[threadIdx.x]);
+}
+__global__ void k_band_fields(const uint8_t *cls, int c0, int c1, uint64_t *packed, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) packed[i] = (cls[i] == c0 ? 1ull : 0ull) | (cls[i] == c1 ? (1ull << 32) : 0ull);
+}
+// stable scatter of the hits of classes c0 / c1 into their own lists; the last thread leaves the counts
+__global__ void k_band_scatter(const uint8_t *cls, int c0, int c1, const uint64_t *scanned, const int32_t *hit_pairs,
+                               int32_t *items, int64_t cap, int32_t *count, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cls[i];
+    const uint32_t r0 = (uint32_t)scanned[i], r1 = (uint32_t)(scanned[i] >> 32);
+    if (c == c0) items[(int64_t)c0 * cap + r0] = hit_pairs[i];
+    else if (c == c1) items[(int64_t)c1 * cap + r1] = hit_pairs[i];
+    if (i == n - 1) {
+        count[c0] = (int32_t)(r0 + (c == c0 ? 1 : 0));
+        if (c1 != c0) count[c1] = (int32_t)(r1 + (c == c1 ? 1 : 0));
     }
 }
 
@@ -546,7 +706,8 @@ void ultra_myers_free(ultra_ctx *ctx)
     MyersState &st = ctx->my;
     DevBuf *bufs[] = {&st.seq, &st.rseq, &st.qoff, &st.qlen, &st.toff, &st.tlen, &st.k, &st.ed, &st.nloc, &st.slots,
                       &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
-                      &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff};
+                      &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff,
+                      &st.bandcls, &st.banditems, &st.bandinfo};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto &mc : st.classes) { if (mc.ev0) (void)hipEventDestroy(mc.ev0); if (mc.ev1) (void)hipEventDestroy(mc.ev1); }
@@ -750,8 +911,86 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
     a.ops_off = want_ops ? st.opsoff.as<int64_t>() : nullptr;
     const size_t budget = (size_t)16 << 30; // trace scratch budget (bytes)
+    const int64_t n_hits = st.total_hit;
+    int32_t h_band[2 * (kBandClasses + 1)]; // counts, then longest first location, per band class
+    for (auto &v : h_band) v = 0;
+    const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0;
+    a.band_cls = nullptr;
+    if (use_band) {
+        // 3a: banded kernels for every hit whose distance fits a band of at most 512 rows
+        const int np = st.S + 1 <= 8 ? 3 : 5; // bit-planes of (code + 1)
+        const size_t NH = (size_t)n_hits;
+        ULTRA_HIP_CHECK(ctx, st.bandcls.ensure(NH + 64));
+        ULTRA_HIP_CHECK(ctx, st.banditems.ensure(NH * 4 * (kBandClasses + 1)));
+        ULTRA_HIP_CHECK(ctx, st.bandinfo.ensure(256));
+        ULTRA_HIP_CHECK(ctx, st.packed.ensure(NH * 8)); ULTRA_HIP_CHECK(ctx, st.scanned.ensure(NH * 8));
+        int32_t *d_count = st.bandinfo.as<int32_t>(), *d_maxl = d_count + (kBandClasses + 1);
+        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bandinfo.p, 0, 256, s));
+        const unsigned gb = (unsigned)((n_hits + 255) / 256);
+        hipLaunchKernelGGL(k_band_classify, dim3(gb), dim3(256), 0, s, a, n_hits, 1, st.bandcls.as<uint8_t>(), d_maxl);
+        for (int c0 = 0; c0 <= kBandClasses; c0 += 2) {
+            const int c1 = c0 + 1 <= kBandClasses ? c0 + 1 : c0;
+            hipLaunchKernelGGL(k_band_fields, dim3(gb), dim3(256), 0, s, st.bandcls.as<uint8_t>(), c0, c1, st.packed.as<uint64_t>(), n_hits);
+            ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, st.packed.as<uint64_t>(), st.scanned.as<uint64_t>(), n_hits, st.blocksum));
+            hipLaunchKernelGGL(k_band_scatter, dim3(gb), dim3(256), 0, s, st.bandcls.as<uint8_t>(), c0, c1, st.scanned.as<uint64_t>(),
+                               a.hit_pairs, st.banditems.as<int32_t>(), n_hits, d_count, n_hits);
+        }
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_band, st.bandinfo.p, sizeof h_band, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        // one scratch buffer, split between the band classes so that their launches can overlap
+        int64_t units[kBandClasses], region[kBandClasses];
+        size_t total_entries = 0;
+        for (int c = 0; c < kBandClasses; c++) {
+            const int WB = 1 << c;
+            units[c] = region[c] = 0;
+            if (h_band[c] <= 0) continue;
+            region[c] = (int64_t)h_band[kBandClasses + 1 + c] * WB * 64;
+            const int64_t waves = ((int64_t)h_band[c] + 63) / 64;
+            int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * 16);
+            u = std::min<int64_t>(u, std::max<int64_t>(4, (int64_t)((budget / kBandClasses) / (size_t)(region[c] * 16))));
+            u = (u + 3) / 4 * 4; // whole blocks of 4 waves
+            units[c] = u;
+            total_entries += (size_t)region[c] * (size_t)u;
+        }
+        ULTRA_HIP_CHECK(ctx, st.trace.ensure(total_entries * 16 + 64));
+        ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+        size_t at = 0;
+        for (int c = kBandClasses - 1; c >= 0; c--) {
+            if (h_band[c] <= 0) continue;
+            MyArgs b = a;
+            b.tr = st.trace.as<ulonglong2>() + at;
+            b.region = region[c];
+            at += (size_t)region[c] * (size_t)units[c];
+            const int32_t *items = st.banditems.as<int32_t>() + (int64_t)c * n_hits;
+            const dim3 grid((unsigned)(units[c] / 4)), block(256);
+            hipStream_t cs = ctx->aux[c % kAuxStreams];
+            const int64_t ni = h_band[c];
+            if (np == 3) {
+                switch (c) {
+                case 0: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, 0, cs, b, items, ni); break;
+                case 1: hipLaunchKernelGGL((myers_band<2, 3>), grid, block, 0, cs, b, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_band<4, 3>), grid, block, 0, cs, b, items, ni); break;
+                default: hipLaunchKernelGGL((myers_band<8, 3>), grid, block, 0, cs, b, items, ni); break;
+                }
+            } else {
+                switch (c) {
+                case 0: hipLaunchKernelGGL((myers_band<1, 5>), grid, block, 0, cs, b, items, ni); break;
+                case 1: hipLaunchKernelGGL((myers_band<2, 5>), grid, block, 0, cs, b, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_band<4, 5>), grid, block, 0, cs, b, items, ni); break;
+                default: hipLaunchKernelGGL((myers_band<8, 5>), grid, block, 0, cs, b, items, ni); break;
+                }
+            }
+            ULTRA_HIP_CHECK(ctx, hipGetLastError());
+        }
+        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // the fallback below may re-size the scratch buffer
+        a.band_cls = st.bandcls.as<uint8_t>();
+    }
+    // 3b: full-height kernels for what is left (distance > 254, or edit scripts wanted, or banding off)
+    const bool need_full = !use_band || h_band[kBandFallback] > 0;
     for (auto &mc : st.classes) {
-        if (mc.he <= mc.hb) continue;
+        if (!need_full || mc.he <= mc.hb) continue;
         int cls = class_of(64 * mc.G * mc.W);
         const int NB = mc.G * mc.W;
         // first location: L = end - start + 1 <= m + ed <= m + k, and k <= m (clamped in setup_item)
