@@ -54,7 +54,7 @@ struct MyersState {
     float ms[4] = {0, 0, 0, 0};
     int64_t total_loc = 0, total_hit = 0;
     DevBuf seq, rseq, qoff, qlen, toff, tlen, k, ed, nloc, slots, packed, scanned, blocksum, locoff, hitoff,
-        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo;
+        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

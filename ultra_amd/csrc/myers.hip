@@ -18,7 +18,10 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstring>
 #include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -379,6 +382,8 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
 // traceback state {Pv, Ph} is WB words per column instead of ceil(m/64).  No Peq table: the window's
 // match vector is rebuilt from NP bit-planes of the query codes that slide with the window.
 // Window of column c: bit b <-> query row c - TOP + b, TOP = 32*WB - 1; needs ed <= 32*WB - 2.
+constexpr int kBandStage = 8;  // columns staged in LDS per refill of the walk
+
 template <int WB, int NP>
 __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items, int64_t n_items)
 {
@@ -386,6 +391,8 @@ __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int64_t gwave = (int64_t)blockIdx.x * wpb + wave, nwaves = (int64_t)gridDim.x * wpb;
     ulonglong2 *T = a.tr + gwave * a.region + lane; // entry (column c, word w) at T[(c * WB + w) * 64]
+    extern __shared__ ulonglong2 band_lds[];
+    ulonglong2 *stage = band_lds + (size_t)wave * kBandStage * 2 * 64 + lane; // staged (column k, word u) of this lane at stage[(k * SW + u) * 64]
     for (int64_t base = gwave * 64; base < n_items; base += nwaves * 64) {
         const bool valid = base + lane < n_items;
         int p = 0, m = 0, L = 0;
@@ -464,14 +471,32 @@ __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items
             }
             insert_row();
         }
-        __threadfence();
+        // ---- walk (every lane reads back only what it wrote itself) ----
+        // The walk moves through the columns backwards, so it stages kStage columns of the current
+        // word at a time in LDS: kStage independent loads in flight instead of one dependent load
+        // per step.
         if (valid) {
-            int r = m - 1, c = L - 1, ins = 0, cw = -1, cc = -1;
-            ulonglong2 e = {0, 0};
+            constexpr int SW = WB > 1 ? 2 : 1; // staged words per column: the path may hover around a word boundary
+            int r = m - 1, c = L - 1, ins = 0;
+            int win_hi = -1, win_lo = 0x7fffffff, wlo = 0, blo = 0, bhi = -1;
             while (r >= 0 && c >= 0) {
                 const int b = r - c + TOP;
-                const int w = b >> 6;
-                if (w != cw || c != cc) { e = T[((int64_t)c * WB + w) * 64]; cw = w; cc = c; }
+                if (c < win_lo || b < blo || b > bhi) {
+                    if (SW == 2) { wlo = (b - 32) >> 6; wlo = wlo < 0 ? 0 : (wlo > WB - 2 ? WB - 2 : wlo); }
+                    blo = 64 * wlo; bhi = blo + 64 * SW - 1;
+                    // fixed trip count (columns below 0 are clamped): all loads are issued before the first LDS write
+                    ulonglong2 buf[kBandStage * SW];
+#pragma unroll
+                    for (int k = 0; k < kBandStage; k++) {
+                        const int ck = c - k > 0 ? c - k : 0;
+#pragma unroll
+                        for (int u = 0; u < SW; u++) buf[k * SW + u] = T[((int64_t)ck * WB + wlo + u) * 64];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kBandStage * SW; k++) stage[k * 64] = buf[k];
+                    win_hi = c; win_lo = c - kBandStage + 1;
+                }
+                const ulonglong2 e = stage[((win_hi - c) * SW + (SW == 2 ? ((b - blo) >> 6) : 0)) * 64];
                 const uint64_t bit = ((uint64_t)1) << (b & 63);
                 if (e.x & bit) { ins++; r--; }
                 else if (e.y & bit) c--;
@@ -480,50 +505,44 @@ __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items
             if (r >= 0) ins += r + 1;
             a.first_ins[p] = ins;
         }
-        __threadfence();
     }
 }
 
 
-// class of every hit by its distance (band rows needed: 2*ed + 3) + per-class longest first location
-__global__ void __launch_bounds__(256) k_band_classify(MyArgs a, int64_t n_hits, int allow, uint8_t *cls, int32_t *max_l)
+// Sort key of every hit: band class by its distance (band rows needed: 2*ed + 3), then the length
+// of its first location, longest first - the lanes of a wavefront then run equally long.
+constexpr uint32_t kBandLBits = 24;
+__global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys)
 {
-    __shared__ int32_t sh[kBandClasses + 1];
-    if (threadIdx.x <= kBandClasses) sh[threadIdx.x] = 0;
-    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_hits) {
-        const int32_t p = a.hit_pairs[i];
-        const int ed = a.ed[p];
-        const int64_t lo = a.loc_off[p];
-        const int L = a.loc_end[lo] - a.loc_start[lo] + 1;
-        int c = ed <= 30 ? 0 : ed <= 62 ? 1 : ed <= 126 ? 2 : ed <= 254 ? 3 : kBandFallback;
-        if (!allow) c = kBandFallback;
-        cls[i] = (uint8_t)c;
-        atomicMax(&sh[c], L);
-    }
-    __syncthreads();
-    if (threadIdx.x <= kBandClasses && sh[threadIdx.x] > 0) atomicMax(&max_l[threadIdx.x], sh[threadIdx.x]);
+    if (i >= n_hits) return;
+    const int32_t p = a.hit_pairs[i];
+    const int ed = a.ed[p];
+    const int64_t lo = a.loc_off[p];
+    const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
+    const uint32_t c = ed <= 30 ? 0 : ed <= 62 ? 1 : ed <= 126 ? 2 : ed <= 254 ? 3 : kBandFallback;
+    keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
 }
-__global__ void k_band_fields(const uint8_t *cls, int c0, int c1, uint64_t *packed, int64_t n)
+// info[c] = first sorted position of class c (c = 0 .. kBandClasses + 1), info[6 + c] = its longest first location
+__global__ void k_band_bounds(const uint32_t *keys, int64_t n, int32_t *info)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) packed[i] = (cls[i] == c0 ? 1ull : 0ull) | (cls[i] == c1 ? (1ull << 32) : 0ull);
-}
-// stable scatter of the hits of classes c0 / c1 into their own lists; the last thread leaves the counts
-__global__ void k_band_scatter(const uint8_t *cls, int c0, int c1, const uint64_t *scanned, const int32_t *hit_pairs,
-                               int32_t *items, int64_t cap, int32_t *count, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = cls[i];
-    const uint32_t r0 = (uint32_t)scanned[i], r1 = (uint32_t)(scanned[i] >> 32);
-    if (c == c0) items[(int64_t)c0 * cap + r0] = hit_pairs[i];
-    else if (c == c1) items[(int64_t)c1 * cap + r1] = hit_pairs[i];
-    if (i == n - 1) {
-        count[c0] = (int32_t)(r0 + (c == c0 ? 1 : 0));
-        if (c1 != c0) count[c1] = (int32_t)(r1 + (c == c1 ? 1 : 0));
+    const int c = threadIdx.x;
+    if (c > kBandClasses + 1) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((keys[mid] >> kBandLBits) < (uint32_t)c) lo = mid + 1; else hi = mid;
     }
+    info[c] = (int32_t)lo;
+    int32_t maxl = 0;
+    if (lo < n && (keys[lo] >> kBandLBits) == (uint32_t)c) maxl = (int32_t)(((1u << kBandLBits) - 1u) - (keys[lo] & ((1u << kBandLBits) - 1u)));
+    info[kBandClasses + 2 + c] = maxl;
+}
+// band class of every hit in hit-list order, for the full-height kernels' skip test
+__global__ void k_band_cls(const uint32_t *keys, uint8_t *cls, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cls[i] = (uint8_t)(keys[i] >> kBandLBits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -707,7 +726,7 @@ void ultra_myers_free(ultra_ctx *ctx)
     DevBuf *bufs[] = {&st.seq, &st.rseq, &st.qoff, &st.qlen, &st.toff, &st.tlen, &st.k, &st.ed, &st.nloc, &st.slots,
                       &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
                       &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff,
-                      &st.bandcls, &st.banditems, &st.bandinfo};
+                      &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto &mc : st.classes) { if (mc.ev0) (void)hipEventDestroy(mc.ev0); if (mc.ev1) (void)hipEventDestroy(mc.ev1); }
@@ -918,26 +937,33 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     a.band_cls = nullptr;
     if (use_band) {
         // 3a: banded kernels for every hit whose distance fits a band of at most 512 rows
-        const int np = st.S + 1 <= 8 ? 3 : 5; // bit-planes of (code + 1)
         const size_t NH = (size_t)n_hits;
         ULTRA_HIP_CHECK(ctx, st.bandcls.ensure(NH + 64));
-        ULTRA_HIP_CHECK(ctx, st.banditems.ensure(NH * 4 * (kBandClasses + 1)));
+        ULTRA_HIP_CHECK(ctx, st.banditems.ensure(NH * 4 * 4)); // keys in | keys out | items out
         ULTRA_HIP_CHECK(ctx, st.bandinfo.ensure(256));
-        ULTRA_HIP_CHECK(ctx, st.packed.ensure(NH * 8)); ULTRA_HIP_CHECK(ctx, st.scanned.ensure(NH * 8));
-        int32_t *d_count = st.bandinfo.as<int32_t>(), *d_maxl = d_count + (kBandClasses + 1);
-        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bandinfo.p, 0, 256, s));
+        uint32_t *k_in = st.banditems.as<uint32_t>(), *k_out = k_in + NH;
+        int32_t *items_sorted = (int32_t *)(k_out + NH);
         const unsigned gb = (unsigned)((n_hits + 255) / 256);
-        hipLaunchKernelGGL(k_band_classify, dim3(gb), dim3(256), 0, s, a, n_hits, 1, st.bandcls.as<uint8_t>(), d_maxl);
-        for (int c0 = 0; c0 <= kBandClasses; c0 += 2) {
-            const int c1 = c0 + 1 <= kBandClasses ? c0 + 1 : c0;
-            hipLaunchKernelGGL(k_band_fields, dim3(gb), dim3(256), 0, s, st.bandcls.as<uint8_t>(), c0, c1, st.packed.as<uint64_t>(), n_hits);
-            ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, st.packed.as<uint64_t>(), st.scanned.as<uint64_t>(), n_hits, st.blocksum));
-            hipLaunchKernelGGL(k_band_scatter, dim3(gb), dim3(256), 0, s, st.bandcls.as<uint8_t>(), c0, c1, st.scanned.as<uint64_t>(),
-                               a.hit_pairs, st.banditems.as<int32_t>(), n_hits, d_count, n_hits);
+        hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in);
+        hipLaunchKernelGGL(k_band_cls, dim3(gb), dim3(256), 0, s, k_in, st.bandcls.as<uint8_t>(), n_hits);
+        {
+            size_t tmp_bytes = 0;
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 3, s));
+            ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 3, s));
         }
+        hipLaunchKernelGGL(k_band_bounds, dim3(1), dim3(64), 0, s, k_out, n_hits, st.bandinfo.as<int32_t>());
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_band, st.bandinfo.p, sizeof h_band, hipMemcpyDeviceToHost, s));
+        int32_t h_info[2 * (kBandClasses + 2)];
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, sizeof h_info, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        int32_t band_first[kBandClasses + 1];
+        for (int c = 0; c <= kBandClasses; c++) {
+            band_first[c] = h_info[c];
+            h_band[c] = h_info[c + 1] - h_info[c];
+            h_band[kBandClasses + 1 + c] = h_info[kBandClasses + 2 + c];
+        }
+        const int np = st.S + 1 <= 8 ? 3 : 5; // bit-planes of (code + 1)
         // one scratch buffer, split between the band classes so that their launches can overlap
         int64_t units[kBandClasses], region[kBandClasses];
         size_t total_entries = 0;
@@ -962,23 +988,24 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             b.tr = st.trace.as<ulonglong2>() + at;
             b.region = region[c];
             at += (size_t)region[c] * (size_t)units[c];
-            const int32_t *items = st.banditems.as<int32_t>() + (int64_t)c * n_hits;
+            const int32_t *items = items_sorted + band_first[c];
             const dim3 grid((unsigned)(units[c] / 4)), block(256);
             hipStream_t cs = ctx->aux[c % kAuxStreams];
             const int64_t ni = h_band[c];
+            const size_t band_lds = (size_t)4 * kBandStage * 2 * 64 * sizeof(ulonglong2);
             if (np == 3) {
                 switch (c) {
-                case 0: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, 0, cs, b, items, ni); break;
-                case 1: hipLaunchKernelGGL((myers_band<2, 3>), grid, block, 0, cs, b, items, ni); break;
-                case 2: hipLaunchKernelGGL((myers_band<4, 3>), grid, block, 0, cs, b, items, ni); break;
-                default: hipLaunchKernelGGL((myers_band<8, 3>), grid, block, 0, cs, b, items, ni); break;
+                case 0: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                case 1: hipLaunchKernelGGL((myers_band<2, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_band<4, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                default: hipLaunchKernelGGL((myers_band<8, 3>), grid, block, band_lds, cs, b, items, ni); break;
                 }
             } else {
                 switch (c) {
-                case 0: hipLaunchKernelGGL((myers_band<1, 5>), grid, block, 0, cs, b, items, ni); break;
-                case 1: hipLaunchKernelGGL((myers_band<2, 5>), grid, block, 0, cs, b, items, ni); break;
-                case 2: hipLaunchKernelGGL((myers_band<4, 5>), grid, block, 0, cs, b, items, ni); break;
-                default: hipLaunchKernelGGL((myers_band<8, 5>), grid, block, 0, cs, b, items, ni); break;
+                case 0: hipLaunchKernelGGL((myers_band<1, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                case 1: hipLaunchKernelGGL((myers_band<2, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_band<4, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                default: hipLaunchKernelGGL((myers_band<8, 5>), grid, block, band_lds, cs, b, items, ni); break;
                 }
             }
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
