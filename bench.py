@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=8192, help="reads (instances) per step and per GPU")
+    ap.add_argument("--reads", type=int, default=131072, help="reads (instances) per step and per GPU")
     ap.add_argument("--preset", default="ont_cdna", choices=["ont_cdna", "isoseq", "ont_drna"])
     ap.add_argument("--genes", type=int, default=1500)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
@@ -180,14 +180,17 @@ def main():
             ops_per_launch = OPS_PER_CELL * c / launches
             dur = ms / launches * 1e-3
             achieved = ops_per_launch / dur * 1e-12
-            traffic = None
+            kname = "myers_lane<%d, 0>" % Wd if G == 1 else "myers_group<%d, %d, 0>" % (G, Wd)
+            traffic = None  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (profiles/)
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    rec = json.load(open(pmc))
+                    if rec.get("dominant_kernel") == kname:
+                        traffic = rec.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = {"bound": "valu_int32", "kernel": "myers forward G=%d W=%d" % (G, Wd), "achieved": achieved,
+            roof = {"bound": "valu_int32", "kernel": kname, "achieved": achieved,
                     "peak": peak_ops * 1e-12, "unit": "Tops/s", "frac": achieved / (peak_ops * 1e-12),
                     "traffic": traffic, "cells_per_launch": c / launches, "avg_launch_ms": ms / launches,
                     "ops_per_cell": OPS_PER_CELL,
