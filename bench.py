@@ -145,15 +145,8 @@ def main():
     t1 = time.perf_counter()
     out = stage.results_to_python(batch, res)
     topy_s = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(len(insts)), float(cells)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        reads_all, cells_all = float(tot[0].item()), float(tot[1].item())
-    else:
-        reads_all, cells_all = float(len(insts)), float(cells)
+    from ultra_amd import shard
+    elapsed, reads_all, cells_all = shard.reduce_job(elapsed, len(insts), cells, device="cuda" if world > 1 else None)
 
     # ---- parity spot check of the timed output (oracle = checker only) ---------------------------
     checked = 0
