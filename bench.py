@@ -173,7 +173,7 @@ def main():
             ops_per_launch = OPS_PER_CELL * c / launches
             dur = ms / launches * 1e-3
             achieved = ops_per_launch / dur * 1e-12
-            kname = "myers_lane<%d, 0>" % Wd if G == 1 else "myers_group<%d, %d, 0>" % (G, Wd)
+            kname = "myers_mega<0, %d>" % G   # forward pass (MODE 0) of register bucket G
             traffic = None  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (profiles/)
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
@@ -207,6 +207,9 @@ def main():
             "outside_timed_region": {"fetch_results_pcie_ms": fetch_s * 1e3, "python_tuples_ms": topy_s * 1e3,
                                      "reads_per_s_incl_fetch": reads_all / world / (elapsed / K + fetch_s),
                                      "chain_rows_fetched": int(res["chain_off"][-1])},
+            "forward_buckets": {"bucket%d_wmax%d" % k: {"cells_per_step": v[0] / v[2], "ms_per_step": v[1] / v[2],
+                                                        "tcups": v[0] / v[1] * 1e-9 if v[1] > 0 else None}
+                                for k, v in sorted(class_ms.items())},
             "device": info, "parity_checked_instances": checked,
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -105,9 +105,10 @@ int ultra_myers_fetch(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
  * stage: [0] forward (distance + end positions), [1] reverse (start positions), [2] traceback,
  * [3] everything (first launch to last completion).  Measured with HIP events on the ctx stream. */
 int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[4]);
-/* Per size class of the last _run (a class = one kernel instantiation: G lanes per pair x W 64-row
- * words per lane): forward-pass cells and device milliseconds of that class's forward launch.
- * Fills up to cap entries, *n_classes = number of classes of the batch. For roofline reports. */
+/* Per register bucket of the last _run (a bucket = one forward kernel, myers_mega<FWD, bucket>, covering
+ * the size classes up to W 64-row words per lane; bucket 3 = multi-lane classes for queries > 512):
+ * G[i] = bucket id, W[i] = its widest class, forward-pass cells of its pairs and device milliseconds
+ * of its forward launch.  Fills up to cap entries, *n_classes = number of non-empty buckets. */
 int ultra_myers_class_timing(const ultra_ctx *ctx, int32_t cap, int32_t *G, int32_t *W, double *cells, float *fwd_ms,
                              int32_t *n_classes);
 

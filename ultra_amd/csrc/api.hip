@@ -102,12 +102,14 @@ int ultra_myers_class_timing(const ultra_ctx *ctx, int32_t cap, int32_t *G, int3
 {
     if (!ctx || !ctx->my.ran) return ULTRA_E_STATE;
     if (!n_classes || cap < 0 || (cap > 0 && (!G || !W || !cells || !fwd_ms))) return ULTRA_E_ARG;
-    int32_t n = (int32_t)ctx->my.classes.size();
-    *n_classes = n;
-    for (int32_t i = 0; i < n && i < cap; i++) {
-        const MyersClass &mc = ctx->my.classes[(size_t)i];
-        G[i] = mc.G; W[i] = mc.W; cells[i] = mc.cells; fwd_ms[i] = mc.fwd_ms;
+    int32_t n = 0;
+    for (int b = 0; b < 4; b++) {
+        const MyersBucket &bk = ctx->my.buckets[b];
+        if (bk.n_fwd <= 0) continue;
+        if (n < cap) { G[n] = b; W[n] = bk.wmax; cells[n] = bk.cells; fwd_ms[n] = bk.fwd_ms; }
+        n++;
     }
+    *n_classes = n;
     return ULTRA_OK;
 }
 

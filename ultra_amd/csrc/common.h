@@ -37,8 +37,23 @@ struct MyersClass {
     int64_t lb, le;     // location (CSR) range, known after the forward pass
     int64_t hb, he;     // hit (ed >= 0) range
     double cells;       // forward-pass cells of the class (sum of q_len * t_len)
-    float fwd_ms;       // device time of the class's forward launch in the last run
-    hipEvent_t ev0, ev1;
+};
+
+// One work item of a pass = one wavefront: items [base, min(base + per_wave, end)) of size class cls.
+struct WorkItem {
+    int64_t base, end;
+    int32_t cls;
+    int32_t cost;
+};
+
+// Register bucket of size classes: one launch per pass and bucket (myers_mega<MODE, BUCKET>).
+struct MyersBucket {
+    DevBuf fwd_list, rev_list;
+    int32_t n_fwd = 0, n_rev = 0;
+    int wmax = 0;
+    double cells = 0;   // forward-pass cells (sum of q_len * t_len) of the bucket's pairs
+    float fwd_ms = 0;   // device time of the bucket's forward launch in the last run
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 struct MyersState {
@@ -48,6 +63,8 @@ struct MyersState {
     int S = 0;          // alphabet size of the batch (distinct bytes)
     std::vector<int32_t> perm;      // sorted position -> caller's pair index
     std::vector<MyersClass> classes;
+    MyersBucket buckets[4];
+    std::vector<WorkItem> h_work[4];
     std::vector<int64_t> h_qoff, h_toff;
     std::vector<int32_t> h_qlen, h_tlen, h_k;
     double cells = 0;

@@ -172,23 +172,19 @@ __device__ __forceinline__ void traceback(const ulonglong2 *tr, int64_t stride, 
 // ------------------------------------------------------------------------------------------------
 // lane-per-pair kernel: W words per lane in registers
 // ------------------------------------------------------------------------------------------------
+// One wavefront's worth of work: items [base, base + 64) (clipped to a.end).  lds_wave: S*W*64 words
+// private to the wavefront; gwave: index of the wavefront's trace region (MODE_NW only).
 template <int W, int MODE>
-__global__ void __launch_bounds__(256) myers_lane(MyArgs a)
+__device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_t *lds_wave, int64_t gwave)
 {
-    extern __shared__ uint64_t lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int waves_per_block = blockDim.x >> 6;
-    const int64_t gwave = (int64_t)blockIdx.x * waves_per_block + wave;
-    const int64_t nwaves = (int64_t)gridDim.x * waves_per_block;
     const int S = a.S;
-    uint64_t *peq = lds + (size_t)wave * S * W * 64 + lane; // word (sym, b) at peq[(sym*W + b)*64]
+    uint64_t *peq = lds_wave + lane; // word (sym, b) at peq[(sym*W + b)*64]
     constexpr int ROWS = 64 * W;
-
-    for (int64_t base = a.begin + gwave * 64; base < a.end; base += nwaves * 64) {
+    {
         Item it = setup_item<MODE>(a, base + lane);
         if (MODE == MODE_FWD_EXACT || MODE == MODE_NW) {
-            if (!__any(it.valid)) continue;
+            if (!__any(it.valid)) return;
         }
         const int pad = ROWS - it.m;
         // ---- Peq into LDS (lane-private words: no synchronisation needed) ----
@@ -275,25 +271,36 @@ __global__ void __launch_bounds__(256) myers_lane(MyArgs a)
     }
 }
 
+template <int W, int MODE>
+__global__ void __launch_bounds__(256) myers_lane(MyArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int64_t gwave = (int64_t)blockIdx.x * waves_per_block + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * waves_per_block;
+    uint64_t *lds_wave = lds + (size_t)wave * a.S * W * 64;
+    for (int64_t base = a.begin + gwave * 64; base < a.end; base += nwaves * 64) lane_item<W, MODE>(a, base, lds_wave, gwave);
+}
+
 // ------------------------------------------------------------------------------------------------
 // lane-group kernel: G lanes per pair, W words per lane, skewed (anti-diagonal) schedule
 // ------------------------------------------------------------------------------------------------
+// One wavefront's worth of work: items [base, base + 64/G).  slot0: first trace slot of the wavefront (MODE_NW).
 template <int G, int W, int MODE>
-__global__ void __launch_bounds__(64) myers_group(MyArgs a)
+__device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64_t *lds_wave, int64_t slot0)
 {
-    extern __shared__ uint64_t lds[];
     constexpr int P = 64 / G;    // pairs per wave
     constexpr int NB = G * W;    // words per pair
     constexpr int ROWS = 64 * NB;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int g = lane % G, p = lane / G;
     const int S = a.S;
-    uint64_t *peq = lds + (size_t)p * S * NB; // word (sym, blk) at peq[sym*NB + blk]
-
-    for (int64_t base = a.begin + (int64_t)blockIdx.x * P; base < a.end; base += (int64_t)gridDim.x * P) {
+    uint64_t *peq = lds_wave + (size_t)p * S * NB; // word (sym, blk) at peq[sym*NB + blk]
+    {
         Item it = setup_item<MODE>(a, base + p);
         if (MODE == MODE_FWD_EXACT || MODE == MODE_NW) {
-            if (!__any(it.valid)) continue;
+            if (!__any(it.valid)) return;
         }
         const int pad = ROWS - it.m;
         const uint64_t padfill_on = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ~(uint64_t)0 : 0;
@@ -317,17 +324,23 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
         if (MODE == MODE_FWD) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
         if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
         ulonglong2 *tT = nullptr;
-        if (MODE == MODE_NW) tT = a.tr + ((int64_t)blockIdx.x * P + p) * a.region;
+        if (MODE == MODE_NW) tT = a.tr + (slot0 + p) * a.region;
         const int n = it.valid ? it.n : 0;
         const int nmax = wave_max_i32(n);
         const int steps = nmax + G - 1;
-        uint32_t hp_out = 0, hm_out = 0;
+        uint32_t h_out = 0; // bit 0: +1 carry out of this lane's last word, bit 1: -1 carry
+        uint64_t tw = 0;    // this lane's next target bytes (its column lags g steps behind lane 0)
         for (int t = 0; t < steps; t++) {
-            uint32_t hp = __shfl_up(hp_out, 1, 64), hm = __shfl_up(hm_out, 1, 64);
-            if (g == 0) { hp = top_hp; hm = 0; }
+            // the carry moves one lane down per step: a DPP row shift inside a 16-lane group, a shuffle otherwise
+            uint32_t h_in = G <= 16 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x111 /* row_shr:1 */, 0xf, 0xf, false)
+                                    : (uint32_t)__shfl_up((int)h_out, 1, 64);
+            if (g == 0) h_in = top_hp;
+            uint32_t hp = h_in & 1u, hm = h_in >> 1;
             const int col = t - g;
             if (col >= 0 && col < n) {
-                const int code = (int)it.t[col];
+                if ((col & 7) == 0) tw = load8(it.t + col);
+                const int code = (int)(tw & 0xff);
+                tw >>= 8;
                 const uint64_t *pe = peq + (size_t)code * NB + g * W;
 #pragma unroll
                 for (int w = 0; w < W; w++) {
@@ -338,7 +351,7 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
                         tT[(int64_t)col * NB + g * W + w] = e;
                     }
                 }
-                hp_out = hp; hm_out = hm;
+                h_out = hp | (hm << 1);
                 if (g == G - 1) {
                     score += (int32_t)hp - (int32_t)hm;
                     if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
@@ -368,6 +381,52 @@ __global__ void __launch_bounds__(64) myers_group(MyArgs a)
                 if (a.n_ops) a.n_ops[it.pair] = nops;
             }
             __threadfence();
+        }
+    }
+}
+
+template <int G, int W, int MODE>
+__global__ void __launch_bounds__(64) myers_group(MyArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    constexpr int P = 64 / G;
+    for (int64_t base = a.begin + (int64_t)blockIdx.x * P; base < a.end; base += (int64_t)gridDim.x * P)
+        group_item<G, W, MODE>(a, base, lds, (int64_t)blockIdx.x * P);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one launch per pass: every wavefront takes one work item (64 pairs of one size class)
+// ------------------------------------------------------------------------------------------------
+// The size classes differ 100x in work per wavefront.  Launching them one after the other leaves the
+// chip nearly empty while the few long-running wavefronts of the big classes finish, so a pass is
+// ONE grid per register bucket: work items sorted heaviest first (workgroups are dispatched in
+// index order), one wavefront per workgroup, each jumping to the code of its class.
+template <int MODE, int BUCKET>
+__global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list, int32_t n)
+{
+    extern __shared__ uint64_t lds[];
+    if ((int32_t)blockIdx.x >= n) return;
+    const WorkItem wi = list[blockIdx.x];
+    a.end = wi.end;
+    if (BUCKET == 0) {
+        if (wi.cls == 0) lane_item<1, MODE>(a, wi.base, lds, 0); else lane_item<2, MODE>(a, wi.base, lds, 0);
+    } else if (BUCKET == 1) {
+        if (wi.cls == 2) lane_item<3, MODE>(a, wi.base, lds, 0); else lane_item<4, MODE>(a, wi.base, lds, 0);
+    } else if (BUCKET == 2) {
+        switch (wi.cls) {
+        case 4: lane_item<5, MODE>(a, wi.base, lds, 0); break;
+        case 5: lane_item<6, MODE>(a, wi.base, lds, 0); break;
+        case 6: lane_item<7, MODE>(a, wi.base, lds, 0); break;
+        default: lane_item<8, MODE>(a, wi.base, lds, 0); break;
+        }
+    } else {
+        switch (wi.cls) {
+        case 8: group_item<4, 4, MODE>(a, wi.base, lds, 0); break;
+        case 9: group_item<8, 4, MODE>(a, wi.base, lds, 0); break;
+        case 10: group_item<64, 1, MODE>(a, wi.base, lds, 0); break;
+        case 11: group_item<64, 2, MODE>(a, wi.base, lds, 0); break;
+        case 12: group_item<64, 4, MODE>(a, wi.base, lds, 0); break;
+        default: group_item<64, 8, MODE>(a, wi.base, lds, 0); break;
         }
     }
 }
@@ -555,10 +614,13 @@ __global__ void k_reverse(const uint8_t *src, uint8_t *dst, int64_t n)
 }
 
 // packed[i] = (hit << 40) | nloc  so one scan yields both CSR offsets
-__global__ void k_pack(const int32_t *ed, const int32_t *nloc, uint64_t *packed, int32_t n)
+__global__ void k_pack(const int32_t *ed, const int32_t *nloc, uint64_t *packed, int32_t n, int slot_cap, int64_t *overflow)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) packed[i] = (ed[i] >= 0 ? (((uint64_t)1) << 40) : 0) | (uint64_t)(uint32_t)nloc[i];
+    if (i < n) {
+        packed[i] = (ed[i] >= 0 ? (((uint64_t)1) << 40) : 0) | (uint64_t)(uint32_t)nloc[i];
+        if (nloc[i] > slot_cap) *overflow = 1; // rare; every writer stores the same value
+    }
 }
 
 constexpr int SCAN_BLOCK = 1024;
@@ -626,7 +688,7 @@ struct ClassDef { int G, W; };
 // rows = 64*G*W ascending
 const ClassDef kClasses[] = {
     {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 7}, {1, 8},
-    {16, 1}, {16, 2}, {64, 1}, {64, 2}, {64, 4}, {64, 8},
+    {4, 4}, {8, 4}, {64, 1}, {64, 2}, {64, 4}, {64, 8},
 };
 constexpr int kNumClasses = sizeof(kClasses) / sizeof(kClasses[0]);
 constexpr int kMaxQuery = 64 * 64 * 8;
@@ -677,14 +739,62 @@ template <int MODE> hipError_t launch_class(hipStream_t ctx, int cls, const MyAr
     case 5: return launch_lane<6, MODE>(ctx, a, items, max_par);
     case 6: return launch_lane<7, MODE>(ctx, a, items, max_par);
     case 7: return launch_lane<8, MODE>(ctx, a, items, max_par);
-    case 8: return launch_group<16, 1, MODE>(ctx, a, items, max_par);
-    case 9: return launch_group<16, 2, MODE>(ctx, a, items, max_par);
+    case 8: return launch_group<4, 4, MODE>(ctx, a, items, max_par);
+    case 9: return launch_group<8, 4, MODE>(ctx, a, items, max_par);
     case 10: return launch_group<64, 1, MODE>(ctx, a, items, max_par);
     case 11: return launch_group<64, 2, MODE>(ctx, a, items, max_par);
     case 12: return launch_group<64, 4, MODE>(ctx, a, items, max_par);
     case 13: return launch_group<64, 8, MODE>(ctx, a, items, max_par);
     }
     return hipErrorInvalidValue;
+}
+
+constexpr int kBuckets = 4;
+inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 8 ? 2 : 3; }
+inline int bucket_wmax(int b) { return b == 0 ? 2 : b == 1 ? 4 : 8; }
+
+// work items of one pass: for every class the item range [b, e) cut into wavefront-sized pieces
+struct PassRange { int cls; int64_t b, e; const int32_t *t_len; };
+
+void build_work(const std::vector<PassRange> &ranges, std::vector<WorkItem> out[kBuckets])
+{
+    for (int b = 0; b < kBuckets; b++) out[b].clear();
+    for (const PassRange &r : ranges) {
+        const int G = kClasses[r.cls].G, W = kClasses[r.cls].W;
+        const int per = 64 / G;
+        const int rows = 64 * G * W;
+        for (int64_t i = r.b; i < r.e; i += per) {
+            WorkItem wi;
+            wi.base = i; wi.end = r.e; wi.cls = r.cls;
+            // cost ~ words per lane x columns; without target lengths (start pass) columns ~ rows
+            const int64_t last = std::min<int64_t>(i + per, r.e) - 1;
+            const int64_t cols = r.t_len ? r.t_len[last] : rows;
+            wi.cost = (int32_t)std::min<int64_t>((int64_t)W * (cols + G), 0x7fffffff);
+            out[bucket_of(r.cls)].push_back(wi);
+        }
+    }
+    for (int b = 0; b < kBuckets; b++)
+        std::stable_sort(out[b].begin(), out[b].end(), [](const WorkItem &x, const WorkItem &y) { return x.cost > y.cost; });
+}
+
+template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, const MyArgs &a, int bucket, const WorkItem *d_list, int32_t n)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t shmem = (size_t)a.S * bucket_wmax(bucket) * 64 * sizeof(uint64_t);
+    hipStream_t cs = ctx->aux[bucket % kAuxStreams];
+    const void *fn = bucket == 0 ? (const void *)myers_mega<MODE, 0> : bucket == 1 ? (const void *)myers_mega<MODE, 1>
+                   : bucket == 2 ? (const void *)myers_mega<MODE, 2> : (const void *)myers_mega<MODE, 3>;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    switch (bucket) {
+    case 0: hipLaunchKernelGGL((myers_mega<MODE, 0>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
+    case 1: hipLaunchKernelGGL((myers_mega<MODE, 1>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
+    case 2: hipLaunchKernelGGL((myers_mega<MODE, 2>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
+    default: hipLaunchKernelGGL((myers_mega<MODE, 3>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
+    }
+    return hipGetLastError();
 }
 
 int class_of(int m)
@@ -729,7 +839,11 @@ void ultra_myers_free(ultra_ctx *ctx)
                       &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    for (auto &mc : st.classes) { if (mc.ev0) (void)hipEventDestroy(mc.ev0); if (mc.ev1) (void)hipEventDestroy(mc.ev1); }
+    for (auto &bk : st.buckets) {
+        bk.fwd_list.release(); bk.rev_list.release();
+        if (bk.ev0) { (void)hipEventDestroy(bk.ev0); bk.ev0 = nullptr; }
+        if (bk.ev1) { (void)hipEventDestroy(bk.ev1); bk.ev1 = nullptr; }
+    }
     st.classes.clear();
 }
 
@@ -778,7 +892,6 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
         if (cls[a] != cls[b]) return cls[a] < cls[b];
         return t_len[a] < t_len[b];
     });
-    for (auto &mc : st.classes) { if (mc.ev0) (void)hipEventDestroy(mc.ev0); if (mc.ev1) (void)hipEventDestroy(mc.ev1); }
     st.classes.clear();
     st.h_qoff.resize(n_pairs); st.h_toff.resize(n_pairs); st.h_qlen.resize(n_pairs); st.h_tlen.resize(n_pairs); st.h_k.resize(n_pairs);
     for (int32_t i = 0; i < n_pairs; i++) {
@@ -789,7 +902,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
         if (st.classes.empty() || st.classes.back().G != kClasses[c].G || st.classes.back().W != kClasses[c].W) {
             MyersClass mc; mc.G = kClasses[c].G; mc.W = kClasses[c].W; mc.pb = i; mc.pe = i; mc.max_t = 0;
             mc.lb = mc.le = mc.hb = mc.he = 0;
-            mc.cells = 0; mc.fwd_ms = 0; mc.ev0 = mc.ev1 = nullptr;
+            mc.cells = 0;
             st.classes.push_back(mc);
         }
         st.classes.back().pe = i + 1;
@@ -825,7 +938,24 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
     }
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // enc/h_* are host temporaries
     for (auto &e : st.ev) if (!e) ULTRA_HIP_CHECK(ctx, hipEventCreate(&e));
-    for (auto &mc : st.classes) { ULTRA_HIP_CHECK(ctx, hipEventCreate(&mc.ev0)); ULTRA_HIP_CHECK(ctx, hipEventCreate(&mc.ev1)); }
+    {
+        // forward work lists (heaviest wavefront first), one per register bucket
+        std::vector<PassRange> ranges;
+        for (auto &mc : st.classes) ranges.push_back(PassRange{class_of(64 * mc.G * mc.W), mc.pb, mc.pe, st.h_tlen.data()});
+        build_work(ranges, st.h_work);
+        for (int b = 0; b < kBuckets; b++) {
+            MyersBucket &bk = st.buckets[b];
+            bk.n_fwd = (int32_t)st.h_work[b].size();
+            bk.wmax = bucket_wmax(b);
+            bk.cells = 0;
+            for (auto &mc : st.classes) if (bucket_of(class_of(64 * mc.G * mc.W)) == b) bk.cells += mc.cells;
+            if (!bk.ev0) { ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev0)); ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev1)); }
+            if (bk.n_fwd <= 0) continue;
+            ULTRA_HIP_CHECK(ctx, bk.fwd_list.ensure(st.h_work[b].size() * sizeof(WorkItem)));
+            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(bk.fwd_list.p, st.h_work[b].data(), st.h_work[b].size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
+        }
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    }
     st.staged = true;
     return ULTRA_OK;
 }
@@ -855,25 +985,22 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[0], s));
     // ---- pass 1: forward HW ----
     ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
-    {
-        // longest-running classes first
-        int q = 0;
-        for (auto it = st.classes.rbegin(); it != st.classes.rend(); ++it, ++q) {
-            auto &mc = *it;
-            hipStream_t cs = ctx->aux[q % kAuxStreams];
-            a.begin = mc.pb; a.end = mc.pe;
-            int cls = class_of(64 * mc.G * mc.W);
-            ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev0, cs));
-            ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD>(cs, cls, a, mc.pe - mc.pb, 0));
-            ULTRA_HIP_CHECK(ctx, hipEventRecord(mc.ev1, cs));
-        }
+    for (int b = kBuckets - 1; b >= 0; b--) {
+        MyersBucket &bk = st.buckets[b];
+        if (bk.n_fwd <= 0) continue;
+        hipStream_t cs = ctx->aux[b % kAuxStreams];
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev0, cs));
+        ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd));
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev1, cs));
     }
     ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     // ---- CSR offsets ----
-    hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n);
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bounds.as<int64_t>() + 63, 0, 8, s));
+    hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n, a.slot_cap, st.bounds.as<int64_t>() + 63);
     ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, st.packed.as<uint64_t>(), st.scanned.as<uint64_t>(), n, st.blocksum));
     hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, s, st.scanned.as<uint64_t>(), st.packed.as<uint64_t>(),
                        st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), n);
+    int64_t h_overflow = 0;
     {
         // class boundaries (+ totals) to the host: one small copy, the only mid-batch synchronisation
         std::vector<int64_t> pos;
@@ -886,6 +1013,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         hipLaunchKernelGGL(k_gather_bounds, dim3(1), dim3(64), 0, s, st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), dpos, dout, npz);
         std::vector<int64_t> hb((size_t)npz * 2);
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb.data(), dout, npz * 16, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_overflow, st.bounds.as<int64_t>() + 63, 8, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         for (size_t c = 0; c < st.classes.size(); c++) {
             st.classes[c].lb = hb[2 * c]; st.classes[c].le = hb[2 * (c + 1)];
@@ -899,32 +1027,32 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, a.slots, a.slot_cap, a.loc_off,
                        st.hitoff.as<int64_t>(), a.loc_end, st.locpair.as<int32_t>(), st.hitpairs.as<int32_t>(), n);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots ----
-    ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
-    {
-        int q = 0;
-        for (auto it = st.classes.rbegin(); it != st.classes.rend(); ++it, ++q) {
-            auto &mc = *it;
-            a.begin = mc.pb; a.end = mc.pe;
-            int cls = class_of(64 * mc.G * mc.W);
-            ULTRA_HIP_CHECK(ctx, launch_class<MODE_FWD_EXACT>(ctx->aux[q % kAuxStreams], cls, a, mc.pe - mc.pb, 0));
-        }
+    // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare) ----
+    if (h_overflow) {
+        ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+        for (int b = kBuckets - 1; b >= 0; b--)
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), st.buckets[b].n_fwd));
+        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }
-    ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     // ---- pass 2: start positions ----
-    ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
     {
-        int q = 0;
-        for (auto it = st.classes.rbegin(); it != st.classes.rend(); ++it, ++q) {
-            auto &mc = *it;
-            if (mc.le <= mc.lb) continue;
-            a.begin = mc.lb; a.end = mc.le;
-            int cls = class_of(64 * mc.G * mc.W);
-            ULTRA_HIP_CHECK(ctx, launch_class<MODE_REV>(ctx->aux[q % kAuxStreams], cls, a, mc.le - mc.lb, 0));
+        std::vector<PassRange> ranges;
+        for (auto &mc : st.classes)
+            if (mc.le > mc.lb) ranges.push_back(PassRange{class_of(64 * mc.G * mc.W), mc.lb, mc.le, nullptr});
+        build_work(ranges, st.h_work);
+        for (int b = 0; b < kBuckets; b++) {
+            MyersBucket &bk = st.buckets[b];
+            bk.n_rev = (int32_t)st.h_work[b].size();
+            if (bk.n_rev <= 0) continue;
+            ULTRA_HIP_CHECK(ctx, bk.rev_list.ensure(st.h_work[b].size() * sizeof(WorkItem)));
+            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(bk.rev_list.p, st.h_work[b].data(), st.h_work[b].size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
         }
+        ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+        for (int b = kBuckets - 1; b >= 0; b--)
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_REV>(ctx, a, b, st.buckets[b].rev_list.as<WorkItem>(), st.buckets[b].n_rev));
+        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }
-    ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
     // ---- pass 3: first-location traceback ----
     a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
@@ -1057,7 +1185,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[1], st.ev[1], st.ev[2]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[2], st.ev[2], st.ev[3]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[3], st.ev[0], st.ev[3]));
-    for (auto &mc : st.classes) ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&mc.fwd_ms, mc.ev0, mc.ev1));
+    for (auto &bk : st.buckets) { bk.fwd_ms = 0; if (bk.n_fwd > 0) ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&bk.fwd_ms, bk.ev0, bk.ev1)); }
     st.ran = true;
     return ULTRA_OK;
 }
