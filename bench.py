@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--genes", type=int, default=1500)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = min(16, available cores)")
+    ap.add_argument("--contexts", type=int, default=1, help="independent library contexts (host threads) per GPU; "
+                    "each runs 1/N of the step's reads so that the passes of different sub-batches overlap")
     ap.add_argument("--check", type=int, default=64, help="instances of the last step verified against the oracle")
     return ap.parse_args()
 
@@ -111,40 +113,72 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    ctx = lib.Context(local)
+    import threading
+    NC = max(1, args.contexts)
+    ctxs = [lib.Context(local) for _ in range(NC)]
+    ctx = ctxs[0]
     info = ctx.device_info()
-    stage.stage_batch(ctx, batch)
+    if NC == 1:
+        batches = [batch]
+    else:
+        batches = [stage.pack_plans(batch.plans[i::NC]) for i in range(NC)]
+    for c, b in zip(ctxs, batches):
+        stage.stage_batch(c, b)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_all():
+        if NC == 1:
+            stage.run_staged(ctx, P["min_acc"])
+            return
+        errs = []
+
+        def work(c):
+            try:
+                stage.run_staged(c, P["min_acc"])
+            except Exception as e:   # surfaced below
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
     for _ in range(args.warmup):
-        stage.run_staged(ctx, P["min_acc"])
+        run_all()
     class_ms = {}
     fwd_ms = rev_ms = tb_ms = all_ms = 0.0
     build_ms = chain_ms = gather_ms = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stage.run_staged(ctx, P["min_acc"])
-        _, ms = ctx.myers_timing()
-        fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]
-        mm = ctx.mam_timing()
-        build_ms += mm[0]; chain_ms += mm[1]; gather_ms += mm[2]
-        for key, (c, t) in ctx.myers_class_timing().items():
-            a = class_ms.setdefault(key, [0.0, 0.0, 0])
-            a[0] += c; a[1] += t; a[2] += 1
+        run_all()
+        for c in ctxs:
+            _, ms = c.myers_timing()
+            fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]
+            mm = c.mam_timing()
+            build_ms += mm[0]; chain_ms += mm[1]; gather_ms += mm[2]
+            for key, (cc, t) in c.myers_class_timing().items():
+                a = class_ms.setdefault(key, [0.0, 0.0, 0])
+                a[0] += cc; a[1] += t; a[2] += 1
     barrier()
     elapsed = time.perf_counter() - t0
     # results back to the host (PCIe; outside the timed region, reported separately)
     t1 = time.perf_counter()
-    res = ctx.mam_fetch()
+    ress = [c.mam_fetch() for c in ctxs]
     fetch_s = time.perf_counter() - t1
     t1 = time.perf_counter()
-    out = stage.results_to_python(batch, res)
+    outs = [stage.results_to_python(b, r) for b, r in zip(batches, ress)]
     topy_s = time.perf_counter() - t1
+    out = [None] * len(insts)
+    for i in range(NC):
+        out[i::NC] = outs[i]
+    res = {"chain_off": [sum(int(r["chain_off"][-1]) for r in ress)]}
     from ultra_amd import shard
     elapsed, reads_all, cells_all = shard.reduce_job(elapsed, len(insts), cells, device="cuda" if world > 1 else None)
 
@@ -197,7 +231,7 @@ def main():
             "dtype": "u64 bit-vectors / int32 scores (Myers), f64 (chaining)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] synthetic form: ONT-cDNA-like reads (%s, err %.2f, ~%d bp), "
                                    "%d reads/GPU/step, %d genes synthetic annotation" % (args.preset, P["err"], P["len_mean"], args.reads, args.genes),
-                       "reads_per_gpu_per_step": args.reads, "pairs_per_step_per_gpu": batch.n_pairs,
+                       "reads_per_gpu_per_step": args.reads, "contexts_per_gpu": args.contexts, "pairs_per_step_per_gpu": batch.n_pairs,
                        "cells_per_step_per_gpu": cells, "parallelism": "reads sharded, %d rank(s), no collective" % world},
             "myers_gcups_forward": cells_all * K / (fwd_ms * 1e-3) * 1e-9 / 1.0 if fwd_ms > 0 else None,
             "myers_gcups_all_passes": cells_all * K / (all_ms * 1e-3) * 1e-9 if all_ms > 0 else None,
@@ -214,7 +248,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
