@@ -441,17 +441,25 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
 // traceback state {Pv, Ph} is WB words per column instead of ceil(m/64).  No Peq table: the window's
 // match vector is rebuilt from NP bit-planes of the query codes that slide with the window.
 // Window of column c: bit b <-> query row c - TOP + b, TOP = 32*WB - 1; needs ed <= 32*WB - 2.
-constexpr int kBandStage = 8;  // columns staged in LDS per refill of the walk
+//
+// Traceback state never goes through HBM as whole columns: the forward sweep only leaves a
+// checkpoint (Pv, Mv, bit-planes) every K columns; the walk then goes through the chunks backwards,
+// recomputing one chunk's K columns from its checkpoint into LDS ({Pv, Ph} per column) and walking
+// inside LDS.  Twice the (cheap, banded) arithmetic instead of 16*WB bytes per column and lane of
+// HBM traffic plus a dependent load per walk step.
+template <int WB> struct BandK { static constexpr int K = WB <= 1 ? 32 : WB == 2 ? 16 : 8; }; // columns per chunk
 
 template <int WB, int NP>
-__global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items, int64_t n_items)
+__global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items, int64_t n_items)
 {
     constexpr int TOP = 32 * WB - 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const int64_t gwave = (int64_t)blockIdx.x * wpb + wave, nwaves = (int64_t)gridDim.x * wpb;
-    ulonglong2 *T = a.tr + gwave * a.region + lane; // entry (column c, word w) at T[(c * WB + w) * 64]
+    constexpr int K = BandK<WB>::K;
+    constexpr int CPW = (2 + NP) * WB; // 64-bit words per checkpoint and lane
+    const int lane = threadIdx.x;
+    const int64_t gwave = blockIdx.x, nwaves = gridDim.x;
+    uint64_t *CP = (uint64_t *)a.tr + gwave * a.region + lane; // checkpoint (chunk h, word f) at CP[(h * CPW + f) * 64]
     extern __shared__ ulonglong2 band_lds[];
-    ulonglong2 *stage = band_lds + (size_t)wave * kBandStage * 2 * 64 + lane; // staged (column k, word u) of this lane at stage[(k * SW + u) * 64]
+    ulonglong2 *col = band_lds + lane; // (column k of the chunk, word w) at col[(k * WB + w) * 64]
     for (int64_t base = gwave * 64; base < n_items; base += nwaves * 64) {
         const bool valid = base + lane < n_items;
         int p = 0, m = 0, L = 0;
@@ -465,12 +473,8 @@ __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items
             q = a.seq + a.q_off[p];
             t = a.seq + a.t_off[p] + s0;
         }
-        uint64_t PL[NP][WB];
-#pragma unroll
-        for (int k = 0; k < NP; k++)
-#pragma unroll
-            for (int w = 0; w < WB; w++) PL[k][w] = 0;
-        uint64_t qw = 0;
+        uint64_t PL[NP][WB], VP[WB], VN[WB];
+        uint64_t qw = 0, tw = 0;
         int ri = 0; // next query row to enter the window
         auto insert_row = [&]() {
             if ((ri & 7) == 0) qw = ri < m ? load8(q + ri) : 0;
@@ -484,18 +488,8 @@ __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items
                 PL[k][WB - 1] = (PL[k][WB - 1] >> 1) | ((uint64_t)((code1 >> k) & 1u) << 63);
             }
         };
-        for (int i = 0; i <= TOP; i++) insert_row(); // rows 0 .. TOP: the window of column -1
-        // column -1: D[r][-1] = r + 1 for query rows, 0 for the virtual rows above row 0
-        uint64_t VP[WB], VN[WB];
-#pragma unroll
-        for (int w = 0; w < WB; w++) {
-            // bit b <-> row -1 - TOP + b >= 0  <=>  b >= TOP + 1 = 32*WB
-            VP[w] = (64 * w >= TOP + 1) ? ~(uint64_t)0 : (64 * (w + 1) <= TOP + 1 ? 0 : (~(uint64_t)0) << ((TOP + 1) & 63));
-            VN[w] = 0;
-        }
-        const int Lmax = wave_max_i32(L);
-        uint64_t tw = 0;
-        for (int c = 0; c < Lmax; c++) {
+        // one column of the banded recurrence; STORE: leave {Pv, Ph} of the column in LDS slot k
+        auto column = [&](int c, int k, bool store) {
             if ((c & 7) == 0) tw = c < L ? load8(t + c) : 0;
             const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
             tw >>= 8;
@@ -503,10 +497,10 @@ __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items
 #pragma unroll
             for (int w = 0; w < WB; w++) Eq[w] = ~(uint64_t)0;
 #pragma unroll
-            for (int k = 0; k < NP; k++) {
-                const uint64_t mk = ((tc1 >> k) & 1u) ? 0 : ~(uint64_t)0;
+            for (int kk = 0; kk < NP; kk++) {
+                const uint64_t mk = ((tc1 >> kk) & 1u) ? 0 : ~(uint64_t)0;
 #pragma unroll
-                for (int w = 0; w < WB; w++) Eq[w] &= PL[k][w] ^ mk;
+                for (int w = 0; w < WB; w++) Eq[w] &= PL[kk][w] ^ mk;
             }
             uint64_t D0[WB], HP[WB], HN[WB];
             uint64_t carry = 0;
@@ -526,47 +520,74 @@ __global__ void __launch_bounds__(256) myers_band(MyArgs a, const int32_t *items
                 const uint64_t hps = (HP[w] >> 1) | (w + 1 < WB ? (HP[w + 1] << 63) : 0); // Ph in this column's alignment
                 VN[w] = X & HP[w];
                 VP[w] = HN[w] | ~(X | HP[w]);
-                if (c < L) { ulonglong2 e; e.x = VP[w]; e.y = hps; T[((int64_t)c * WB + w) * 64] = e; }
+                if (store) { ulonglong2 e; e.x = VP[w]; e.y = hps; col[(k * WB + w) * 64] = e; }
             }
             insert_row();
+        };
+#pragma unroll
+        for (int k = 0; k < NP; k++)
+#pragma unroll
+            for (int w = 0; w < WB; w++) PL[k][w] = 0;
+        for (int i = 0; i <= TOP; i++) insert_row(); // rows 0 .. TOP: the window of column -1
+        // column -1: D[r][-1] = r + 1 for query rows, 0 for the virtual rows above row 0
+#pragma unroll
+        for (int w = 0; w < WB; w++) {
+            // bit b <-> row -1 - TOP + b >= 0  <=>  b >= TOP + 1 = 32*WB
+            VP[w] = (64 * w >= TOP + 1) ? ~(uint64_t)0 : (64 * (w + 1) <= TOP + 1 ? 0 : (~(uint64_t)0) << ((TOP + 1) & 63));
+            VN[w] = 0;
         }
-        // ---- walk (every lane reads back only what it wrote itself) ----
-        // The walk moves through the columns backwards, so it stages kStage columns of the current
-        // word at a time in LDS: kStage independent loads in flight instead of one dependent load
-        // per step.
-        if (valid) {
-            constexpr int SW = WB > 1 ? 2 : 1; // staged words per column: the path may hover around a word boundary
-            int r = m - 1, c = L - 1, ins = 0;
-            int win_hi = -1, win_lo = 0x7fffffff, wlo = 0, blo = 0, bhi = -1;
-            while (r >= 0 && c >= 0) {
-                const int b = r - c + TOP;
-                if (c < win_lo || b < blo || b > bhi) {
-                    if (SW == 2) { wlo = (b - 32) >> 6; wlo = wlo < 0 ? 0 : (wlo > WB - 2 ? WB - 2 : wlo); }
-                    blo = 64 * wlo; bhi = blo + 64 * SW - 1;
-                    // fixed trip count (columns below 0 are clamped): all loads are issued before the first LDS write
-                    ulonglong2 buf[kBandStage * SW];
+        const int Lmax = wave_max_i32(L);
+        const int nchunk = (Lmax + K - 1) / K;
+        // ---- forward sweep: checkpoints only ----
+        for (int h = 0; h < nchunk; h++) {
+            if (h * K < L) {
+                uint64_t *cp = CP + (int64_t)h * CPW * 64;
 #pragma unroll
-                    for (int k = 0; k < kBandStage; k++) {
-                        const int ck = c - k > 0 ? c - k : 0;
+                for (int w = 0; w < WB; w++) { cp[w * 64] = VP[w]; cp[(WB + w) * 64] = VN[w]; }
 #pragma unroll
-                        for (int u = 0; u < SW; u++) buf[k * SW + u] = T[((int64_t)ck * WB + wlo + u) * 64];
-                    }
+                for (int k = 0; k < NP; k++)
 #pragma unroll
-                    for (int k = 0; k < kBandStage * SW; k++) stage[k * 64] = buf[k];
-                    win_hi = c; win_lo = c - kBandStage + 1;
-                }
-                const ulonglong2 e = stage[((win_hi - c) * SW + (SW == 2 ? ((b - blo) >> 6) : 0)) * 64];
-                const uint64_t bit = ((uint64_t)1) << (b & 63);
-                if (e.x & bit) { ins++; r--; }
-                else if (e.y & bit) c--;
-                else { r--; c--; }
+                    for (int w = 0; w < WB; w++) cp[((2 + k) * WB + w) * 64] = PL[k][w];
             }
-            if (r >= 0) ins += r + 1;
+            if (h + 1 < nchunk) // the last chunk is recomputed first anyway
+                for (int k = 0; k < K; k++) column(h * K + k, k, false);
+        }
+        // ---- backwards through the chunks: recompute into LDS, walk inside LDS ----
+        int r = m - 1, c = L - 1, ins = 0;
+        bool walking = valid;
+        for (int h = nchunk - 1; h >= 0; h--) {
+            const int c0 = h * K;
+            const bool act = walking && c0 < L;
+            if (!__any(act)) continue;
+            if (act) {
+                const uint64_t *cp = CP + (int64_t)h * CPW * 64;
+#pragma unroll
+                for (int w = 0; w < WB; w++) { VP[w] = cp[w * 64]; VN[w] = cp[(WB + w) * 64]; }
+#pragma unroll
+                for (int k = 0; k < NP; k++)
+#pragma unroll
+                    for (int w = 0; w < WB; w++) PL[k][w] = cp[((2 + k) * WB + w) * 64];
+            }
+            ri = TOP + 1 + c0; // rows entered so far (a multiple of 8, like c0: both byte windows refill at once)
+            for (int k = 0; k < K; k++) column(c0 + k, k, true);
+            if (act) {
+                while (r >= 0 && c >= c0) {
+                    const int b = r - c + TOP;
+                    const ulonglong2 e = col[((c - c0) * WB + (b >> 6)) * 64];
+                    const uint64_t bit = ((uint64_t)1) << (b & 63);
+                    if (e.x & bit) { ins++; r--; }
+                    else if (e.y & bit) c--;
+                    else { r--; c--; }
+                }
+                if (r < 0) walking = false; // query used up: only deletions remain
+            }
+        }
+        if (valid) {
+            if (r >= 0) ins += r + 1; // target used up: the remaining query bases are insertions
             a.first_ins[p] = ins;
         }
     }
 }
-
 
 // Sort key of every hit: band class by its distance (band rows needed: 2*ed + 3), then the length
 // of its first location, longest first - the lanes of a wavefront then run equally long.
@@ -1092,35 +1113,40 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             h_band[kBandClasses + 1 + c] = h_info[kBandClasses + 2 + c];
         }
         const int np = st.S + 1 <= 8 ? 3 : 5; // bit-planes of (code + 1)
-        // one scratch buffer, split between the band classes so that their launches can overlap
+        // checkpoint scratch (64-bit words), split between the band classes so that their launches can overlap
         int64_t units[kBandClasses], region[kBandClasses];
-        size_t total_entries = 0;
+        size_t total_words = 0;
         for (int c = 0; c < kBandClasses; c++) {
             const int WB = 1 << c;
+            const int K = WB <= 1 ? 32 : WB == 2 ? 16 : 8;
             units[c] = region[c] = 0;
             if (h_band[c] <= 0) continue;
-            region[c] = (int64_t)h_band[kBandClasses + 1 + c] * WB * 64;
+            const int64_t chunks = ((int64_t)h_band[kBandClasses + 1 + c] + K - 1) / K;
+            region[c] = chunks * (2 + np) * WB * 64;
             const int64_t waves = ((int64_t)h_band[c] + 63) / 64;
-            int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * 16);
-            u = std::min<int64_t>(u, std::max<int64_t>(4, (int64_t)((budget / kBandClasses) / (size_t)(region[c] * 16))));
-            u = (u + 3) / 4 * 4; // whole blocks of 4 waves
+            int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * 10);
+            u = std::min<int64_t>(u, std::max<int64_t>(1, (int64_t)((budget / kBandClasses) / (size_t)(region[c] * 8))));
             units[c] = u;
-            total_entries += (size_t)region[c] * (size_t)u;
+            total_words += (size_t)region[c] * (size_t)u;
         }
-        ULTRA_HIP_CHECK(ctx, st.trace.ensure(total_entries * 16 + 64));
+        ULTRA_HIP_CHECK(ctx, st.trace.ensure(total_words * 8 + 64));
         ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
         size_t at = 0;
         for (int c = kBandClasses - 1; c >= 0; c--) {
             if (h_band[c] <= 0) continue;
             MyArgs b = a;
-            b.tr = st.trace.as<ulonglong2>() + at;
+            b.tr = (ulonglong2 *)(st.trace.as<uint64_t>() + at);
             b.region = region[c];
             at += (size_t)region[c] * (size_t)units[c];
             const int32_t *items = items_sorted + band_first[c];
-            const dim3 grid((unsigned)(units[c] / 4)), block(256);
+            const dim3 grid((unsigned)units[c]), block(64);
             hipStream_t cs = ctx->aux[c % kAuxStreams];
             const int64_t ni = h_band[c];
-            const size_t band_lds = (size_t)4 * kBandStage * 2 * 64 * sizeof(ulonglong2);
+            const size_t band_lds = (size_t)(c == 0 ? 32 : c == 1 ? 32 : c == 2 ? 32 : 64) * 64 * sizeof(ulonglong2); // K * WB columns-words
+            if (band_lds > 64 * 1024) {
+                ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)myers_band<8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
+                ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)myers_band<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
+            }
             if (np == 3) {
                 switch (c) {
                 case 0: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, band_lds, cs, b, items, ni); break;
