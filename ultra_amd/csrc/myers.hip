@@ -36,7 +36,7 @@ struct MyArgs {
     int32_t *ed; int32_t *nloc; int32_t *slots; int slot_cap;
     const int64_t *loc_off; int32_t *loc_end; int32_t *loc_start; const int32_t *loc_pair;
     const int32_t *hit_pairs; int32_t *first_ins;
-    const uint8_t *band_cls; // per hit: band class, or nullptr when the banded traceback is off
+    const int32_t *nw_items; // full-height traceback: dense list of pairs to do, or nullptr = the hit list itself
     ulonglong2 *tr; int64_t region; // trace scratch {Pv, Ph} per word and column; entries per wave (lane kernels) / per pair slot (group kernels)
     int32_t Lmax;
     uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
@@ -76,8 +76,7 @@ template <int MODE> __device__ __forceinline__ Item setup_item(const MyArgs &a, 
         it.q = a.rseq + (a.N - a.q_off[p] - it.m);
         it.t = a.rseq + (a.N - a.t_off[p] - (int64_t)(e + 1));
     } else {
-        int32_t p = a.hit_pairs[item];
-        if (a.band_cls && a.band_cls[item] != kBandFallback) it.valid = false; // handled by the banded kernel
+        int32_t p = a.nw_items ? a.nw_items[item] : a.hit_pairs[item];
         int64_t lo = a.loc_off[p];
         int32_t s = a.loc_start[lo], e = a.loc_end[lo];
         it.pair = p;
@@ -140,16 +139,38 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // step decides it.  stride = distance between consecutive words of one column, colstride = between
 // columns.  Rows above `pad` are top padding: once the query is used up only deletions remain; once
 // the target is used up only insertions remain.
+constexpr int kStage = 8; // columns (x 2 words) staged in LDS per refill of the walk
+
 __device__ __forceinline__ void traceback(const ulonglong2 *tr, int64_t stride, int64_t colstride, int pad, int rows, int L,
-                                          const uint8_t *q, const uint8_t *t, uint8_t *ops, int ops_cap, int &n_ins, int &n_ops)
+                                          const uint8_t *q, const uint8_t *t, uint8_t *ops, int ops_cap, int &n_ins, int &n_ops,
+                                          ulonglong2 *stage)
 {
+    // The walk goes through the columns backwards: kStage columns x 2 adjacent words around the
+    // current row are staged per refill (all loads in flight together) instead of one dependent
+    // HBM load per step.  stage: this lane's slots at stage[i * 64].
+    const int nwords = rows >> 6;
     int ip = rows - 1, c = L - 1;
     int ins = 0, cnt = 0;
-    int cw = -1, cc = -1;
-    ulonglong2 e = {0, 0};
+    int win_hi = -1, win_lo = 0x7fffffff, wlo = 0;
     while (ip >= pad && c >= 0) {
         const int w = ip >> 6;
-        if (w != cw || c != cc) { e = tr[(int64_t)c * colstride + (int64_t)w * stride]; cw = w; cc = c; }
+        if (c < win_lo || w < wlo || w > wlo + 1) {
+            wlo = (ip - 32) >> 6;
+            wlo = wlo > nwords - 2 ? nwords - 2 : wlo;
+            wlo = wlo < 0 ? 0 : wlo;
+            const int w1 = wlo + 1 < nwords ? wlo + 1 : wlo;
+            ulonglong2 buf[kStage * 2];
+#pragma unroll
+            for (int k = 0; k < kStage; k++) {
+                const int ck = c - k > 0 ? c - k : 0;
+                buf[2 * k] = tr[(int64_t)ck * colstride + (int64_t)wlo * stride];
+                buf[2 * k + 1] = tr[(int64_t)ck * colstride + (int64_t)w1 * stride];
+            }
+#pragma unroll
+            for (int k = 0; k < kStage * 2; k++) stage[k * 64] = buf[k];
+            win_hi = c; win_lo = c - kStage + 1;
+        }
+        const ulonglong2 e = stage[((win_hi - c) * 2 + (w - wlo)) * 64];
         const uint64_t bit = ((uint64_t)1) << (ip & 63);
         int code;
         if (e.x & bit) { code = 1; ins++; ip--; }
@@ -262,7 +283,8 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
                 uint8_t *ops = nullptr; int ops_cap = 0;
                 if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
                 int ins, nops;
-                traceback(tT, 64, (int64_t)W * 64, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops);
+                traceback(tT, 64, (int64_t)W * 64, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops,
+                          (ulonglong2 *)(lds_wave + (size_t)S * W * 64) + lane);
                 a.first_ins[it.pair] = ins;
                 if (a.n_ops) a.n_ops[it.pair] = nops;
             }
@@ -279,7 +301,7 @@ __global__ void __launch_bounds__(256) myers_lane(MyArgs a)
     const int waves_per_block = blockDim.x >> 6;
     const int64_t gwave = (int64_t)blockIdx.x * waves_per_block + wave;
     const int64_t nwaves = (int64_t)gridDim.x * waves_per_block;
-    uint64_t *lds_wave = lds + (size_t)wave * a.S * W * 64;
+    uint64_t *lds_wave = lds + (size_t)wave * ((size_t)a.S * W * 64 + (MODE == MODE_NW ? (size_t)kStage * 2 * 64 * 2 : 0));
     for (int64_t base = a.begin + gwave * 64; base < a.end; base += nwaves * 64) lane_item<W, MODE>(a, base, lds_wave, gwave);
 }
 
@@ -376,7 +398,8 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                 uint8_t *ops = nullptr; int ops_cap = 0;
                 if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
                 int ins, nops;
-                traceback(tT, 1, (int64_t)NB, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops);
+                traceback(tT, 1, (int64_t)NB, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops,
+                          (ulonglong2 *)(lds_wave + (size_t)S * NB * P) + lane);
                 a.first_ins[it.pair] = ins;
                 if (a.n_ops) a.n_ops[it.pair] = nops;
             }
@@ -590,8 +613,16 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
 }
 
 // Sort key of every hit: band class by its distance (band rows needed: 2*ed + 3), then the length
-// of its first location, longest first - the lanes of a wavefront then run equally long.
-constexpr uint32_t kBandLBits = 24;
+// of its first location, longest first - the lanes of a wavefront then run equally long.  Hits beyond
+// every band class are keyed by the size class of their query instead: each full-height kernel then
+// gets a dense list of exactly its hits.
+constexpr uint32_t kBandLBits = 24, kFullLBits = 20;
+constexpr int kNumSizeClasses = 14;
+constexpr int kBandBounds = kBandClasses + kNumSizeClasses + 1; // first sorted position of each group, then the end
+__device__ __forceinline__ uint32_t size_class_of(int m)
+{
+    return m <= 512 ? (uint32_t)((m - 1) >> 6) : m <= 1024 ? 8u : m <= 2048 ? 9u : m <= 4096 ? 10u : m <= 8192 ? 11u : m <= 16384 ? 12u : 13u;
+}
 __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,28 +632,30 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
     const int64_t lo = a.loc_off[p];
     const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
     const uint32_t c = ed <= 30 ? 0 : ed <= 62 ? 1 : ed <= 126 ? 2 : ed <= 254 ? 3 : kBandFallback;
-    keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
+    if (c < kBandFallback) keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
+    else keys[i] = (c << kBandLBits) | (size_class_of(a.q_len[p]) << kFullLBits) | (((1u << kFullLBits) - 1u) - (L < (1u << kFullLBits) ? L : (1u << kFullLBits) - 1u));
 }
-// info[c] = first sorted position of class c (c = 0 .. kBandClasses + 1), info[6 + c] = its longest first location
+// info[g] = first sorted position of group g (band classes 0..3, then the 14 size classes of the
+// rest, then the end); info[kBandBounds + c] = longest first location of band class c
 __global__ void k_band_bounds(const uint32_t *keys, int64_t n, int32_t *info)
 {
-    const int c = threadIdx.x;
-    if (c > kBandClasses + 1) return;
+    const int g = threadIdx.x;
+    if (g >= kBandBounds) return;
+    const uint32_t thr = g < kBandClasses ? ((uint32_t)g << kBandLBits)
+                       : g < kBandBounds - 1 ? (((uint32_t)kBandFallback << kBandLBits) | ((uint32_t)(g - kBandClasses) << kFullLBits))
+                                             : 0xffffffffu;
     int64_t lo = 0, hi = n;
+    if (g == kBandBounds - 1) lo = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if ((keys[mid] >> kBandLBits) < (uint32_t)c) lo = mid + 1; else hi = mid;
+        if (keys[mid] < thr) lo = mid + 1; else hi = mid;
     }
-    info[c] = (int32_t)lo;
-    int32_t maxl = 0;
-    if (lo < n && (keys[lo] >> kBandLBits) == (uint32_t)c) maxl = (int32_t)(((1u << kBandLBits) - 1u) - (keys[lo] & ((1u << kBandLBits) - 1u)));
-    info[kBandClasses + 2 + c] = maxl;
-}
-// band class of every hit in hit-list order, for the full-height kernels' skip test
-__global__ void k_band_cls(const uint32_t *keys, uint8_t *cls, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cls[i] = (uint8_t)(keys[i] >> kBandLBits);
+    info[g] = (int32_t)lo;
+    if (g < kBandClasses) {
+        int32_t maxl = 0;
+        if (lo < n && (keys[lo] >> kBandLBits) == (uint32_t)g) maxl = (int32_t)(((1u << kBandLBits) - 1u) - (keys[lo] & ((1u << kBandLBits) - 1u)));
+        info[kBandBounds + g] = maxl;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -719,7 +752,7 @@ constexpr size_t kArenaPad = 64;
 template <int W, int MODE> hipError_t launch_lane(hipStream_t stream, const MyArgs &a, int64_t items, int max_waves)
 {
     int S = a.S;
-    size_t per_wave = (size_t)S * W * 64 * sizeof(uint64_t);
+    size_t per_wave = (size_t)S * W * 64 * sizeof(uint64_t) + (MODE == MODE_NW ? (size_t)kStage * 2 * 64 * sizeof(ulonglong2) : 0);
     int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(64 * 1024) / per_wave));
     size_t shmem = per_wave * wpb;
     if (shmem > 64 * 1024) {
@@ -737,7 +770,7 @@ template <int W, int MODE> hipError_t launch_lane(hipStream_t stream, const MyAr
 template <int G, int W, int MODE> hipError_t launch_group(hipStream_t stream, const MyArgs &a, int64_t items, int max_blocks)
 {
     constexpr int P = 64 / G;
-    size_t shmem = (size_t)P * a.S * G * W * sizeof(uint64_t);
+    size_t shmem = (size_t)P * a.S * G * W * sizeof(uint64_t) + (MODE == MODE_NW ? (size_t)kStage * 2 * 64 * sizeof(ulonglong2) : 0);
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)myers_group<G, W, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
@@ -1083,7 +1116,10 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     int32_t h_band[2 * (kBandClasses + 1)]; // counts, then longest first location, per band class
     for (auto &v : h_band) v = 0;
     const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0;
-    a.band_cls = nullptr;
+    a.nw_items = nullptr;
+    int32_t full_first[kNumSizeClasses + 1];
+    for (auto &v : full_first) v = 0;
+    const int32_t *d_items_sorted = nullptr;
     if (use_band) {
         // 3a: banded kernels for every hit whose distance fits a band of at most 512 rows
         const size_t NH = (size_t)n_hits;
@@ -1094,7 +1130,6 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         int32_t *items_sorted = (int32_t *)(k_out + NH);
         const unsigned gb = (unsigned)((n_hits + 255) / 256);
         hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in);
-        hipLaunchKernelGGL(k_band_cls, dim3(gb), dim3(256), 0, s, k_in, st.bandcls.as<uint8_t>(), n_hits);
         {
             size_t tmp_bytes = 0;
             ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 3, s));
@@ -1103,15 +1138,18 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         }
         hipLaunchKernelGGL(k_band_bounds, dim3(1), dim3(64), 0, s, k_out, n_hits, st.bandinfo.as<int32_t>());
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
-        int32_t h_info[2 * (kBandClasses + 2)];
+        int32_t h_info[kBandBounds + kBandClasses];
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, sizeof h_info, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         int32_t band_first[kBandClasses + 1];
-        for (int c = 0; c <= kBandClasses; c++) {
-            band_first[c] = h_info[c];
+        for (int c = 0; c <= kBandClasses; c++) band_first[c] = h_info[c];
+        for (int c = 0; c < kBandClasses; c++) {
             h_band[c] = h_info[c + 1] - h_info[c];
-            h_band[kBandClasses + 1 + c] = h_info[kBandClasses + 2 + c];
+            h_band[kBandClasses + 1 + c] = h_info[kBandBounds + c];
         }
+        h_band[kBandFallback] = h_info[kBandBounds - 1] - h_info[kBandClasses];
+        for (int c = 0; c <= kNumSizeClasses; c++) full_first[c] = h_info[kBandClasses + c];
+        d_items_sorted = items_sorted;
         const int np = st.S + 1 <= 8 ? 3 : 5; // bit-planes of (code + 1)
         // checkpoint scratch (64-bit words), split between the band classes so that their launches can overlap
         int64_t units[kBandClasses], region[kBandClasses];
@@ -1166,7 +1204,6 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         }
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // the fallback below may re-size the scratch buffer
-        a.band_cls = st.bandcls.as<uint8_t>();
     }
     // 3b: full-height kernels for what is left (distance > 254, or edit scripts wanted, or banding off)
     const bool need_full = !use_band || h_band[kBandFallback] > 0;
@@ -1177,6 +1214,13 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         // first location: L = end - start + 1 <= m + ed <= m + k, and k <= m (clamped in setup_item)
         int64_t Lmax = std::min<int64_t>(mc.max_t, (int64_t)2 * 64 * NB);
         int64_t items = mc.he - mc.hb;
+        a.begin = mc.hb; a.end = mc.he;
+        if (use_band) { // only the hits the banded kernels left, as a dense list
+            a.begin = full_first[cls]; a.end = full_first[cls + 1];
+            a.nw_items = d_items_sorted;
+            items = a.end - a.begin;
+            if (items <= 0) continue;
+        }
         int64_t region, units; // entries per unit (wave for lane kernels, pair slot for group kernels)
         int max_par;
         if (mc.G == 1) {
@@ -1200,7 +1244,6 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ULTRA_HIP_CHECK(ctx, st.trace.ensure((entries + slack) * 16 + 64));
         a.tr = st.trace.as<ulonglong2>();
         a.region = region; a.Lmax = (int32_t)Lmax;
-        a.begin = mc.hb; a.end = mc.he;
         ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(s, cls, a, items, max_par));
         // the scratch buffer may be re-sized by the next class: wait before reuse
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
