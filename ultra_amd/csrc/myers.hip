@@ -241,37 +241,54 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
         if (MODE == MODE_NW) tT = a.tr + gwave * a.region + lane;
         const int n = it.valid ? it.n : 0;
         const int nmax = wave_max_i32(n);
-        uint64_t tw = 0, tnext = (n > 0) ? load8(it.t) : 0;
-        for (int j = 0; j < nmax; j++) {
-            if ((j & 7) == 0) {
-                tw = tnext;
-                if (j + 8 < n) tnext = load8(it.t + j + 8);
-            }
-            if (j < n) {
-                const int code = (int)(tw & 0xff);
-                const uint64_t *pe = peq + (size_t)code * (W * 64);
-                uint32_t hp = top_hp, hm = 0;
+        // Eight columns per target chunk.  The chunks are double-buffered (the load of the next one is
+        // issued a whole block of columns before its first use) and the match words of column j+1 are
+        // read from LDS while column j is computed.
+        auto read_eq = [&](uint64_t *eq, uint64_t chunk, int u, bool ok) {
+            const int code = ok ? (int)((chunk >> (8 * u)) & 0xff) : 0;
+            const uint64_t *pe = peq + (size_t)code * (W * 64);
 #pragma unroll
-                for (int b = 0; b < W; b++) {
-                    uint64_t ph0;
-                    word_step(Pv[b], Mv[b], pe[b * 64], hp, hm, ph0);
-                    if (MODE == MODE_NW) {
-                        ulonglong2 e; e.x = Pv[b]; e.y = ph0;
-                        tT[((int64_t)j * W + b) * 64] = e;
+            for (int b = 0; b < W; b++) eq[b] = pe[b * 64];
+        };
+        auto block8 = [&](uint64_t chunk, int j0) {
+            uint64_t eq[W], eqn[W];
+            read_eq(eq, chunk, 0, j0 < n);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u;
+                if (u < 7) read_eq(eqn, chunk, u + 1, j + 1 < n);
+                if (j < n) {
+                    uint32_t hp = top_hp, hm = 0;
+#pragma unroll
+                    for (int b = 0; b < W; b++) {
+                        uint64_t ph0;
+                        word_step(Pv[b], Mv[b], eq[b], hp, hm, ph0);
+                        if (MODE == MODE_NW) {
+                            ulonglong2 e; e.x = Pv[b]; e.y = ph0;
+                            tT[((int64_t)j * W + b) * 64] = e;
+                        }
+                    }
+                    score += (int32_t)hp - (int32_t)hm;
+                    if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
+                        if (score <= lim) {
+                            if (score < best) { best = score; cnt = 0; lim = score; }
+                            if (cnt < out_cap) out[cnt] = j;
+                            cnt++;
+                        }
+                    } else if (MODE == MODE_REV) {
+                        if (score <= it.best) last = j;
                     }
                 }
-                score += (int32_t)hp - (int32_t)hm;
-                if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
-                    if (score <= lim) {
-                        if (score < best) { best = score; cnt = 0; lim = score; }
-                        if (cnt < out_cap) out[cnt] = j;
-                        cnt++;
-                    }
-                } else if (MODE == MODE_REV) {
-                    if (score <= it.best) last = j;
-                }
+#pragma unroll
+                for (int b = 0; b < W; b++) eq[b] = eqn[b];
             }
-            tw >>= 8;
+        };
+        uint64_t ca = (n > 0) ? load8(it.t) : 0, cb = 0;
+        for (int j0 = 0; j0 < nmax; j0 += 16) {
+            if (j0 + 8 < n) cb = load8(it.t + j0 + 8);
+            block8(ca, j0);
+            if (j0 + 16 < n) ca = load8(it.t + j0 + 16);
+            if (j0 + 8 < nmax) block8(cb, j0 + 8);
         }
         if (MODE == MODE_FWD) {
             if (it.valid) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
