@@ -103,7 +103,7 @@ int ultra_myers_class_timing(const ultra_ctx *ctx, int32_t cap, int32_t *G, int3
     if (!ctx || !ctx->my.ran) return ULTRA_E_STATE;
     if (!n_classes || cap < 0 || (cap > 0 && (!G || !W || !cells || !fwd_ms))) return ULTRA_E_ARG;
     int32_t n = 0;
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < 5; b++) {
         const MyersBucket &bk = ctx->my.buckets[b];
         if (bk.n_fwd <= 0) continue;
         if (n < cap) { G[n] = b; W[n] = bk.wmax; cells[n] = bk.cells; fwd_ms[n] = bk.fwd_ms; }

@@ -63,8 +63,8 @@ struct MyersState {
     int S = 0;          // alphabet size of the batch (distinct bytes)
     std::vector<int32_t> perm;      // sorted position -> caller's pair index
     std::vector<MyersClass> classes;
-    MyersBucket buckets[4];
-    std::vector<WorkItem> h_work[4];
+    MyersBucket buckets[5];
+    std::vector<WorkItem> h_work[5];
     std::vector<int64_t> h_qoff, h_toff;
     std::vector<int32_t> h_qlen, h_tlen, h_k;
     double cells = 0;

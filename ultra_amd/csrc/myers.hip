@@ -453,19 +453,14 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
     } else if (BUCKET == 1) {
         if (wi.cls == 2) lane_item<3, MODE>(a, wi.base, lds, 0); else lane_item<4, MODE>(a, wi.base, lds, 0);
     } else if (BUCKET == 2) {
-        switch (wi.cls) {
-        case 4: lane_item<5, MODE>(a, wi.base, lds, 0); break;
-        case 5: lane_item<6, MODE>(a, wi.base, lds, 0); break;
-        case 6: lane_item<7, MODE>(a, wi.base, lds, 0); break;
-        default: lane_item<8, MODE>(a, wi.base, lds, 0); break;
-        }
+        if (wi.cls == 4) group_item<2, 3, MODE>(a, wi.base, lds, 0); else group_item<2, 4, MODE>(a, wi.base, lds, 0);
+    } else if (BUCKET == 3) {
+        if (wi.cls == 6) group_item<4, 4, MODE>(a, wi.base, lds, 0); else group_item<8, 4, MODE>(a, wi.base, lds, 0);
     } else {
         switch (wi.cls) {
-        case 8: group_item<4, 4, MODE>(a, wi.base, lds, 0); break;
-        case 9: group_item<8, 4, MODE>(a, wi.base, lds, 0); break;
-        case 10: group_item<64, 1, MODE>(a, wi.base, lds, 0); break;
-        case 11: group_item<64, 2, MODE>(a, wi.base, lds, 0); break;
-        case 12: group_item<64, 4, MODE>(a, wi.base, lds, 0); break;
+        case 8: group_item<64, 1, MODE>(a, wi.base, lds, 0); break;
+        case 9: group_item<64, 2, MODE>(a, wi.base, lds, 0); break;
+        case 10: group_item<64, 4, MODE>(a, wi.base, lds, 0); break;
         default: group_item<64, 8, MODE>(a, wi.base, lds, 0); break;
         }
     }
@@ -634,11 +629,12 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
 // every band class are keyed by the size class of their query instead: each full-height kernel then
 // gets a dense list of exactly its hits.
 constexpr uint32_t kBandLBits = 24, kFullLBits = 20;
-constexpr int kNumSizeClasses = 14;
+constexpr int kNumSizeClasses = 12;
 constexpr int kBandBounds = kBandClasses + kNumSizeClasses + 1; // first sorted position of each group, then the end
 __device__ __forceinline__ uint32_t size_class_of(int m)
 {
-    return m <= 512 ? (uint32_t)((m - 1) >> 6) : m <= 1024 ? 8u : m <= 2048 ? 9u : m <= 4096 ? 10u : m <= 8192 ? 11u : m <= 16384 ? 12u : 13u;
+    return m <= 256 ? (uint32_t)((m - 1) >> 6) : m <= 384 ? 4u : m <= 512 ? 5u : m <= 1024 ? 6u : m <= 2048 ? 7u
+         : m <= 4096 ? 8u : m <= 8192 ? 9u : m <= 16384 ? 10u : 11u;
 }
 __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys)
 {
@@ -758,8 +754,9 @@ __global__ void k_fill(const int32_t *ed, const int32_t *nloc, const int32_t *sl
 struct ClassDef { int G, W; };
 // rows = 64*G*W ascending
 const ClassDef kClasses[] = {
-    {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 7}, {1, 8},
-    {4, 4}, {8, 4}, {64, 1}, {64, 2}, {64, 4}, {64, 8},
+    {1, 1}, {1, 2}, {1, 3}, {1, 4},       // <= 256 rows: lane per pair
+    {2, 3}, {2, 4}, {4, 4}, {8, 4},       // 384, 512, 1024, 2048 rows: 2..8 lanes per pair
+    {64, 1}, {64, 2}, {64, 4}, {64, 8},   // 4096 .. 32768 rows: wavefront per pair
 };
 constexpr int kNumClasses = sizeof(kClasses) / sizeof(kClasses[0]);
 constexpr int kMaxQuery = 64 * 64 * 8;
@@ -806,23 +803,21 @@ template <int MODE> hipError_t launch_class(hipStream_t ctx, int cls, const MyAr
     case 1: return launch_lane<2, MODE>(ctx, a, items, max_par);
     case 2: return launch_lane<3, MODE>(ctx, a, items, max_par);
     case 3: return launch_lane<4, MODE>(ctx, a, items, max_par);
-    case 4: return launch_lane<5, MODE>(ctx, a, items, max_par);
-    case 5: return launch_lane<6, MODE>(ctx, a, items, max_par);
-    case 6: return launch_lane<7, MODE>(ctx, a, items, max_par);
-    case 7: return launch_lane<8, MODE>(ctx, a, items, max_par);
-    case 8: return launch_group<4, 4, MODE>(ctx, a, items, max_par);
-    case 9: return launch_group<8, 4, MODE>(ctx, a, items, max_par);
-    case 10: return launch_group<64, 1, MODE>(ctx, a, items, max_par);
-    case 11: return launch_group<64, 2, MODE>(ctx, a, items, max_par);
-    case 12: return launch_group<64, 4, MODE>(ctx, a, items, max_par);
-    case 13: return launch_group<64, 8, MODE>(ctx, a, items, max_par);
+    case 4: return launch_group<2, 3, MODE>(ctx, a, items, max_par);
+    case 5: return launch_group<2, 4, MODE>(ctx, a, items, max_par);
+    case 6: return launch_group<4, 4, MODE>(ctx, a, items, max_par);
+    case 7: return launch_group<8, 4, MODE>(ctx, a, items, max_par);
+    case 8: return launch_group<64, 1, MODE>(ctx, a, items, max_par);
+    case 9: return launch_group<64, 2, MODE>(ctx, a, items, max_par);
+    case 10: return launch_group<64, 4, MODE>(ctx, a, items, max_par);
+    case 11: return launch_group<64, 8, MODE>(ctx, a, items, max_par);
     }
     return hipErrorInvalidValue;
 }
 
-constexpr int kBuckets = 4;
-inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 8 ? 2 : 3; }
-inline int bucket_wmax(int b) { return b == 0 ? 2 : b == 1 ? 4 : 8; }
+constexpr int kBuckets = 5;
+inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 8 ? 3 : 4; }
+inline int bucket_wmax(int b) { return b == 0 ? 2 : b < 4 ? 4 : 8; } // words per lane: LDS per wavefront = S * wmax * 512 B
 
 // work items of one pass: for every class the item range [b, e) cut into wavefront-sized pieces
 struct PassRange { int cls; int64_t b, e; const int32_t *t_len; };
@@ -854,7 +849,8 @@ template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, const MyArgs &a, int 
     const size_t shmem = (size_t)a.S * bucket_wmax(bucket) * 64 * sizeof(uint64_t);
     hipStream_t cs = ctx->aux[bucket % kAuxStreams];
     const void *fn = bucket == 0 ? (const void *)myers_mega<MODE, 0> : bucket == 1 ? (const void *)myers_mega<MODE, 1>
-                   : bucket == 2 ? (const void *)myers_mega<MODE, 2> : (const void *)myers_mega<MODE, 3>;
+                   : bucket == 2 ? (const void *)myers_mega<MODE, 2> : bucket == 3 ? (const void *)myers_mega<MODE, 3>
+                                                                                     : (const void *)myers_mega<MODE, 4>;
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
@@ -863,7 +859,8 @@ template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, const MyArgs &a, int 
     case 0: hipLaunchKernelGGL((myers_mega<MODE, 0>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
     case 1: hipLaunchKernelGGL((myers_mega<MODE, 1>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
     case 2: hipLaunchKernelGGL((myers_mega<MODE, 2>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
-    default: hipLaunchKernelGGL((myers_mega<MODE, 3>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
+    case 3: hipLaunchKernelGGL((myers_mega<MODE, 3>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
+    default: hipLaunchKernelGGL((myers_mega<MODE, 4>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
     }
     return hipGetLastError();
 }
