@@ -71,7 +71,7 @@ struct MyersState {
     float ms[4] = {0, 0, 0, 0};
     int64_t total_loc = 0, total_hit = 0;
     DevBuf seq, rseq, qoff, qlen, toff, tlen, k, ed, nloc, slots, packed, scanned, blocksum, locoff, hitoff,
-        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp;
+        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

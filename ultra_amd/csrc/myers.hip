@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
 // recomputing one chunk's K columns from its checkpoint into LDS ({Pv, Ph} per column) and walking
 // inside LDS.  Twice the (cheap, banded) arithmetic instead of 16*WB bytes per column and lane of
 // HBM traffic plus a dependent load per walk step.
-template <int WB> struct BandK { static constexpr int K = WB <= 1 ? 32 : WB == 2 ? 16 : 8; }; // columns per chunk
+template <int WB> struct BandK { static constexpr int K = WB <= 1 ? 16 : 8; }; // columns per chunk
 
 template <int WB, int NP>
 __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items, int64_t n_items)
@@ -904,7 +904,7 @@ void ultra_myers_free(ultra_ctx *ctx)
     DevBuf *bufs[] = {&st.seq, &st.rseq, &st.qoff, &st.qlen, &st.toff, &st.tlen, &st.k, &st.ed, &st.nloc, &st.slots,
                       &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
                       &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff,
-                      &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp};
+                      &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp, &st.trace2};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto &bk : st.buckets) {
@@ -1131,6 +1131,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     for (auto &v : h_band) v = 0;
     const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0;
     a.nw_items = nullptr;
+    bool forked = false;
     int32_t full_first[kNumSizeClasses + 1];
     for (auto &v : full_first) v = 0;
     const int32_t *d_items_sorted = nullptr;
@@ -1170,7 +1171,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         size_t total_words = 0;
         for (int c = 0; c < kBandClasses; c++) {
             const int WB = 1 << c;
-            const int K = WB <= 1 ? 32 : WB == 2 ? 16 : 8;
+            const int K = WB <= 1 ? 16 : 8;
             units[c] = region[c] = 0;
             if (h_band[c] <= 0) continue;
             const int64_t chunks = ((int64_t)h_band[kBandClasses + 1 + c] + K - 1) / K;
@@ -1183,6 +1184,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         }
         ULTRA_HIP_CHECK(ctx, st.trace.ensure(total_words * 8 + 64));
         ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+        forked = true;
         size_t at = 0;
         for (int c = kBandClasses - 1; c >= 0; c--) {
             if (h_band[c] <= 0) continue;
@@ -1194,7 +1196,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             const dim3 grid((unsigned)units[c]), block(64);
             hipStream_t cs = ctx->aux[c % kAuxStreams];
             const int64_t ni = h_band[c];
-            const size_t band_lds = (size_t)(c == 0 ? 32 : c == 1 ? 32 : c == 2 ? 32 : 64) * 64 * sizeof(ulonglong2); // K * WB columns-words
+            const size_t band_lds = (size_t)(c == 0 ? 16 : c == 1 ? 16 : c == 2 ? 32 : 64) * 64 * sizeof(ulonglong2); // K * WB columns-words
             if (band_lds > 64 * 1024) {
                 ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)myers_band<8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
                 ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)myers_band<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
@@ -1216,52 +1218,65 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             }
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
         }
-        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
-        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // the fallback below may re-size the scratch buffer
     }
-    // 3b: full-height kernels for what is left (distance > 254, or edit scripts wanted, or banding off)
+    // 3b: full-height kernels for what is left (distance > 254, or edit scripts wanted, or banding off).
+    //     Their own scratch buffer, split between the classes that have work; the launches overlap with
+    //     each other and with the banded ones (these are bound by their critical path, not by the ALUs).
     const bool need_full = !use_band || h_band[kBandFallback] > 0;
-    for (auto &mc : st.classes) {
-        if (!need_full || mc.he <= mc.hb) continue;
-        int cls = class_of(64 * mc.G * mc.W);
-        const int NB = mc.G * mc.W;
-        // first location: L = end - start + 1 <= m + ed <= m + k, and k <= m (clamped in setup_item)
-        int64_t Lmax = std::min<int64_t>(mc.max_t, (int64_t)2 * 64 * NB);
-        int64_t items = mc.he - mc.hb;
-        a.begin = mc.hb; a.end = mc.he;
-        if (use_band) { // only the hits the banded kernels left, as a dense list
-            a.begin = full_first[cls]; a.end = full_first[cls + 1];
-            a.nw_items = d_items_sorted;
-            items = a.end - a.begin;
-            if (items <= 0) continue;
+    if (need_full) {
+        struct FullPlan { int cls; int64_t region, items, begin, end, Lmax; int max_par; size_t entries; };
+        std::vector<FullPlan> plans;
+        for (auto &mc : st.classes) {
+            if (mc.he <= mc.hb) continue;
+            FullPlan fp;
+            fp.cls = class_of(64 * mc.G * mc.W);
+            fp.begin = mc.hb; fp.end = mc.he;
+            if (use_band) { fp.begin = full_first[fp.cls]; fp.end = full_first[fp.cls + 1]; } // dense list of what the banded kernels left
+            fp.items = fp.end - fp.begin;
+            if (fp.items <= 0) continue;
+            plans.push_back(fp);
         }
-        int64_t region, units; // entries per unit (wave for lane kernels, pair slot for group kernels)
-        int max_par;
-        if (mc.G == 1) {
-            region = Lmax * mc.W * 64;
-            int64_t waves = (items + 63) / 64;
-            units = std::min<int64_t>(waves, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 16))));
-            units = std::min<int64_t>(units, (int64_t)ctx->prop.multiProcessorCount * 16);
-            max_par = (int)units;
-        } else {
-            const int P = 64 / mc.G;
-            region = Lmax * NB;
-            int64_t blocks = (items + P - 1) / P;
-            int64_t b = std::min<int64_t>(blocks, std::max<int64_t>(1, (int64_t)(budget / (size_t)(region * 16 * P))));
-            b = std::min<int64_t>(b, (int64_t)ctx->prop.multiProcessorCount * 32);
-            max_par = (int)b;
-            units = b * P;
+        size_t total = 0;
+        for (auto &fp : plans) {
+            const int G = kClasses[fp.cls].G, W = kClasses[fp.cls].W, NB = G * W;
+            int32_t max_t = 0;
+            for (auto &mc : st.classes) if (class_of(64 * mc.G * mc.W) == fp.cls) max_t = mc.max_t;
+            // first location: L = end - start + 1 <= m + ed <= m + k, and k <= m (clamped in setup_item)
+            fp.Lmax = std::min<int64_t>(max_t, (int64_t)2 * 64 * NB);
+            const size_t share = budget / plans.size();
+            if (G == 1) {
+                fp.region = fp.Lmax * W * 64;
+                int64_t waves = (fp.items + 63) / 64;
+                int64_t units = std::min<int64_t>(waves, std::max<int64_t>(1, (int64_t)(share / (size_t)(fp.region * 16))));
+                units = std::min<int64_t>(units, (int64_t)ctx->prop.multiProcessorCount * 16);
+                fp.max_par = (int)units;
+                fp.entries = (size_t)fp.region * (size_t)(units + 4); // the grid is rounded up to whole blocks
+            } else {
+                const int P = 64 / G;
+                fp.region = fp.Lmax * NB;
+                int64_t blocks = (fp.items + P - 1) / P;
+                int64_t b = std::min<int64_t>(blocks, std::max<int64_t>(1, (int64_t)(share / (size_t)(fp.region * 16 * P))));
+                b = std::min<int64_t>(b, (int64_t)ctx->prop.multiProcessorCount * 32);
+                fp.max_par = (int)b;
+                fp.entries = (size_t)fp.region * (size_t)(b * P);
+            }
+            total += fp.entries;
         }
-        size_t entries = (size_t)region * (size_t)units;
-        // lane kernels round the grid up to whole blocks: leave room for up to 3 extra waves
-        size_t slack = (mc.G == 1) ? (size_t)region * 4 : 0;
-        ULTRA_HIP_CHECK(ctx, st.trace.ensure((entries + slack) * 16 + 64));
-        a.tr = st.trace.as<ulonglong2>();
-        a.region = region; a.Lmax = (int32_t)Lmax;
-        ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(s, cls, a, items, max_par));
-        // the scratch buffer may be re-sized by the next class: wait before reuse
-        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        ULTRA_HIP_CHECK(ctx, st.trace2.ensure(total * 16 + 64));
+        if (!forked) { ULTRA_HIP_CHECK(ctx, ultra_fork(ctx)); forked = true; }
+        size_t at = 0;
+        int q = 0;
+        for (auto it = plans.rbegin(); it != plans.rend(); ++it, ++q) {
+            MyArgs b = a;
+            b.tr = st.trace2.as<ulonglong2>() + at;
+            at += it->entries;
+            b.region = it->region; b.Lmax = (int32_t)it->Lmax;
+            b.begin = it->begin; b.end = it->end;
+            b.nw_items = use_band ? d_items_sorted : nullptr;
+            ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->aux[q % kAuxStreams], it->cls, b, it->items, it->max_par));
+        }
     }
+    if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[3], s));
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[0], st.ev[0], st.ev[1]));
