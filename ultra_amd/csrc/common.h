@@ -93,15 +93,18 @@ struct MamState {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
-constexpr int kAuxStreams = 4;
+constexpr int kAuxStreams = 3;  // + the main stream = 4 lanes; a fifth stream would share a hardware queue (4 per process)
+constexpr int kLanes = 4;
 
 struct ultra_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // size classes of one pass are independent: they are launched round-robin on these streams so
     // that short launches overlap (fork = aux streams wait for `stream`, join = `stream` waits for them)
-    hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {nullptr, nullptr, nullptr};
+    // lane i of a forked section: the three auxiliary streams, then the main stream itself
+    hipStream_t lane(int i) const { i %= kLanes; return i < kAuxStreams ? aux[i] : stream; }
     ultra_cfg cfg;
     std::string err;
     hipDeviceProp_t prop;

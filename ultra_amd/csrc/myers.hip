@@ -847,7 +847,7 @@ template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, const MyArgs &a, int 
 {
     if (n <= 0) return hipSuccess;
     const size_t shmem = (size_t)a.S * bucket_wmax(bucket) * 64 * sizeof(uint64_t);
-    hipStream_t cs = ctx->aux[bucket % kAuxStreams];
+    hipStream_t cs = ctx->lane(bucket);
     const void *fn = bucket == 0 ? (const void *)myers_mega<MODE, 0> : bucket == 1 ? (const void *)myers_mega<MODE, 1>
                    : bucket == 2 ? (const void *)myers_mega<MODE, 2> : bucket == 3 ? (const void *)myers_mega<MODE, 3>
                                                                                      : (const void *)myers_mega<MODE, 4>;
@@ -1056,7 +1056,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     for (int b = kBuckets - 1; b >= 0; b--) {
         MyersBucket &bk = st.buckets[b];
         if (bk.n_fwd <= 0) continue;
-        hipStream_t cs = ctx->aux[b % kAuxStreams];
+        hipStream_t cs = ctx->lane(b);
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev0, cs));
         ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd));
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev1, cs));
@@ -1194,7 +1194,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             at += (size_t)region[c] * (size_t)units[c];
             const int32_t *items = items_sorted + band_first[c];
             const dim3 grid((unsigned)units[c]), block(64);
-            hipStream_t cs = ctx->aux[c % kAuxStreams];
+            hipStream_t cs = ctx->lane(c);
             const int64_t ni = h_band[c];
             const size_t band_lds = (size_t)(c == 0 ? 16 : c == 1 ? 16 : c == 2 ? 32 : 64) * 64 * sizeof(ulonglong2); // K * WB columns-words
             if (band_lds > 64 * 1024) {
@@ -1273,7 +1273,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             b.region = it->region; b.Lmax = (int32_t)it->Lmax;
             b.begin = it->begin; b.end = it->end;
             b.nw_items = use_band ? d_items_sorted : nullptr;
-            ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->aux[q % kAuxStreams], it->cls, b, it->items, it->max_par));
+            ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->aux[(q + 1) % kAuxStreams], it->cls, b, it->items, it->max_par));
         }
     }
     if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
