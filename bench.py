@@ -221,6 +221,9 @@ def main():
                     "peak": peak_ops * 1e-12, "unit": "Tops/s", "frac": achieved / (peak_ops * 1e-12),
                     "traffic": traffic, "cells_per_launch": c / launches, "avg_launch_ms": ms / launches,
                     "ops_per_cell": OPS_PER_CELL,
+                    # all forward kernels together (they run concurrently on 4 streams; includes the CSR scan and the exact re-run)
+                    "forward_pass_all_buckets": {"cells_per_step": cells_all / world, "ms_per_step": fwd_ms / K / max(1, args.contexts),
+                                                 "frac": (OPS_PER_CELL * cells_all / world / (fwd_ms / K / max(1, args.contexts) * 1e-3)) / peak_ops if fwd_ms > 0 else None},
                     "hbm": {"algorithmic_bytes_per_step": batch.algorithmic_bytes, "achieved_GBs":
                             batch.algorithmic_bytes / (all_ms / K * 1e-3) * 1e-9 if all_ms > 0 else None,
                             "peak_GBs": HBM_PEAK_GBS}}
