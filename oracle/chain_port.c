@@ -236,3 +236,69 @@ int oracle_chain_batch(int n_inst, const int64_t *inst_off,
     }
     return 0;
 }
+
+/* ============================================================================================== */
+/* NAM (seed) chaining - SURVEY.md section 8 row f1.  The step right before the MAM stage:           */
+/*   read_coverage(mems, max_intron)   /root/reference/modules/colinear_solver.py:169-272  (< 90 NAMs) */
+/*   n_logn_read_coverage(mems)        /root/reference/modules/colinear_solver.py:85-167                 */
+/* called at /root/reference/modules/align.py:448-453.  All-integer objective (read coverage).      */
+/* Both return EVERY co-optimal chain (all_solutions_c_max_indicies :30, reconstruct_all_solutions  */
+/* :49-62); here the DP vectors C[0..n] and trace[0..n] are the output and the (cheap) enumeration  */
+/* of chains is done by the caller.  Pinned against tests/golden/nam_golden.json.                   */
+/* ============================================================================================== */
+
+/* NAMs sorted by y, j = position.  C[0] = 0, trace[0] = -1 (the reference's None). */
+int oracle_nam_quadratic(int n, const int32_t *y, const int32_t *c, const int32_t *d, int64_t max_intron,
+                         int64_t *C, int32_t *trace)
+{
+    C[0] = 0; trace[0] = -1;
+    for (int j = 0; j < n; j++) {
+        int ta = -1, ia = -1;
+        int64_t tmax = 0, imax = 0;
+        for (int jp = j - 1; jp >= 0; jp--) { /* descending: first maximum met = largest j' (:199,:209) */
+            if ((int64_t)y[j] - (int64_t)y[jp] >= max_intron) continue;
+            if (d[jp] < c[j]) {
+                int64_t v = C[jp + 1];
+                if (ta < 0 || v > tmax) { ta = jp; tmax = v; }
+            }
+            if (c[j] <= d[jp] && d[jp] <= d[j]) {
+                int64_t v = C[jp + 1] + (int64_t)(d[j] - d[jp]);
+                if (ia < 0 || v > imax) { ia = jp; imax = v; }
+            }
+        }
+        int64_t Ca = (int64_t)(d[j] - c[j] + 1) + (ta < 0 ? 0 : tmax);
+        int64_t Cb = ia < 0 ? 0 : imax;
+        int jp = Ca >= Cb ? ta : ia; /* max_both: first maximum -> C_a on ties (:232) */
+        C[j + 1] = Ca >= Cb ? Ca : Cb;
+        trace[j + 1] = jp < 0 ? 0 : jp + 1;
+    }
+    return 0;
+}
+
+/* returns 0, or -1 where the reference would print "BUG" and exit */
+int oracle_nam_nlogn(int n, const int32_t *c, const int32_t *d, int64_t *C, int32_t *trace)
+{
+    C[0] = 0; trace[0] = -1;
+    if (n <= 0) return 0;
+    int32_t *ld, *lj;
+    int nleaf = build_leaves(n, d, &ld, &lj);
+    rtree T, I; tree_construct(&T, nleaf, ld, lj); tree_construct(&I, nleaf, ld, lj);
+    int *leaf_of = (int *)malloc(sizeof(int) * n);
+    for (int i = 0; i < nleaf; i++) if (lj[i] >= 0) leaf_of[lj[i]] = i;
+    tree_update(&T, 0, 0.0); tree_update(&I, 0, 0.0);
+    int rc = 0;
+    for (int j = 0; j < n; j++) {
+        double Tmax, Imax; int ja, jb;
+        if (tree_query(&T, -1, c[j] - 1, &Tmax, &ja) != 0 || Tmax < 0) { rc = -1; break; }
+        double Ca = Tmax + (double)(d[j] - c[j] + 1);
+        if (tree_query(&I, c[j], d[j], &Imax, &jb) != 0) { rc = -1; break; }
+        double Cb = Imax + (double)d[j];
+        double v; int jp;
+        if (Cb > Ca) { v = Cb; jp = jb; } else { v = Ca; jp = ja; }
+        C[j + 1] = (int64_t)v;
+        trace[j + 1] = (jp < 0 || v == 0.0) ? 0 : jp + 1;
+        tree_update(&T, leaf_of[j], v); tree_update(&I, leaf_of[j], v - (double)d[j]);
+    }
+    tree_free(&T); tree_free(&I); free(ld); free(lj); free(leaf_of);
+    return rc;
+}

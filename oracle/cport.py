@@ -4,6 +4,7 @@ TEST INFRASTRUCTURE ONLY. Nothing under ultra_amd/ may import this module; only 
 __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
 """
 import ctypes as C
+import ctypes as C_mod
 import os
 import subprocess
 
@@ -148,3 +149,38 @@ def rmq_run(d, upd_j, upd_v, ql, qr):
     if rc != 0:
         raise RuntimeError("oracle rmq_run failed")
     return oc[:nq], oj[:nq], ok[:nq]
+
+
+# ---- NAM chaining -----------------------------------------------------
+def all_optimal_chains(C, trace):
+    """all_solutions_c_max_indicies + reconstruct_all_solutions (colinear_solver.py:30, :49-62) on the DP
+    vectors: every index attaining the maximum, each traced back; returns (list of index lists, value)."""
+    best = max(C)
+    sols = []
+    for idx in [i for i, v in enumerate(C) if v == best]:
+        sol = []
+        while idx > 0:
+            sol.append(idx - 1)
+            idx = trace[idx]
+        sols.append(sol[::-1])
+    return sols, best
+
+
+def nam_quadratic(y, c, d, max_intron):
+    n = len(c)
+    y = np.ascontiguousarray(y, np.int32); c = np.ascontiguousarray(c, np.int32); d = np.ascontiguousarray(d, np.int32)
+    C = np.zeros(n + 1, np.int64); tr = np.zeros(n + 1, np.int32)
+    lib().oracle_nam_quadratic(n, _p(y, C_mod.c_int32), _p(c, C_mod.c_int32), _p(d, C_mod.c_int32), C_mod.c_int64(int(max_intron)),
+                               _p(C, C_mod.c_int64), _p(tr, C_mod.c_int32))
+    return C.tolist(), tr.tolist()
+
+
+def nam_nlogn(c, d):
+    n = len(c)
+    c = np.ascontiguousarray(c, np.int32); d = np.ascontiguousarray(d, np.int32)
+    C = np.zeros(n + 1, np.int64); tr = np.zeros(n + 1, np.int32)
+    lib().oracle_nam_nlogn.restype = C_mod.c_int
+    rc = lib().oracle_nam_nlogn(n, _p(c, C_mod.c_int32), _p(d, C_mod.c_int32), _p(C, C_mod.c_int64), _p(tr, C_mod.c_int32))
+    if rc != 0:
+        raise RuntimeError("oracle nam_nlogn: reference BUG path")
+    return C.tolist(), tr.tolist()
