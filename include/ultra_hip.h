@@ -43,6 +43,7 @@ typedef struct ultra_cfg {
     int32_t loc_slots;        /* end positions kept per pair in the first pass before the exact re-run = 8 */
     int32_t banded_traceback; /* 1 = first-location traceback in a diagonal band sized by the known distance
                                  (same results, far less work); 0 = full-height columns everywhere        = 1 */
+    int32_t nam_switch_n;     /* >= this many NAMs -> n log n NAM solver (align.py:448)                      = 90 */
 } ultra_cfg;
 
 void ultra_cfg_default(ultra_cfg *cfg);
@@ -131,6 +132,32 @@ int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
                            const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
                            const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
                            int32_t *chain_idx, int32_t *chain_len, double *value);
+
+/*
+ * Batched NAM (seed) colinear chaining - the step before the MAM stage.  Replaces
+ *     colinear_solver.read_coverage(mems, max_intron)    (modules/colinear_solver.py:169-272, n < 90)
+ *     colinear_solver.n_logn_read_coverage(mems)         (modules/colinear_solver.py:85-167,  n >= 90)
+ * and the solver switch at modules/align.py:448-453.  The objective is the number of read bases covered,
+ * all arithmetic is integral.
+ *
+ * Instances in CSR form as above; the NAMs of an instance sorted the way align.py hands them over (by y,
+ * help_functions / get_mems_from_input order), j = position inside the instance.  y = reference end of a NAM
+ * (only read by the quadratic solver's intron test, y[j] - y[j'] < max_intron[i]), [c, d] = inclusive read
+ * interval, 0 <= c <= d < 2^30.  max_intron[i]: limit of instance i (align.py:446); y / max_intron may be NULL
+ * when solver == 2.
+ * solver: 0 = pick by cfg.nam_switch_n (reference behaviour), 1 = force quadratic, 2 = force n log n.
+ * The reference returns EVERY co-optimal chain (colinear_solver.py:159-165, :245-270), so the outputs are the
+ * DP vectors themselves, n + 1 entries per instance at index inst_off[i] + i:
+ * out C      C[0] = 0, C[j+1] = best coverage of a chain ending in NAM j
+ * out trace  trace[0] = -1, trace[j+1] = 1 + predecessor NAM, 0 = chain starts here
+ * out value  max(C) of the instance (the reference's second return value)
+ * The co-optimal chains are the back-walks from every j with C[j] == value, in ascending j
+ * (ultra_amd/colinear_solver.py:all_solutions does exactly that).
+ */
+int ultra_chain_nams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
+                           const int32_t *y, const int32_t *c, const int32_t *d,
+                           const int64_t *max_intron, int32_t solver,
+                           int64_t *C, int32_t *trace, int64_t *value);
 
 /*
  * The whole MAM stage of a batch of (read, location) instances in one call, results identical to

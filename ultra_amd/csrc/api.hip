@@ -14,6 +14,7 @@ void ultra_cfg_default(ultra_cfg *cfg)
     cfg->overlap_large = 5;    // classify_read_with_mams.py:563
     cfg->loc_slots = 8;
     cfg->banded_traceback = 1;
+    cfg->nam_switch_n = 90;    // align.py:448
 }
 
 int ultra_device_count(void)

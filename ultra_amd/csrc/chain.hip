@@ -70,6 +70,12 @@ struct ChainArgs {
     uint8_t *work;       // global scratch (n log n)
     const int64_t *work_off;
     int32_t *status;
+    // NAM (seed) chaining, SURVEY.md section 8 row f1: integer read-coverage objective of
+    // colinear_solver.py:85-272; the whole DP vectors are the output (every co-optimal chain is wanted)
+    int32_t nam;               // 0 = MAM objective, 1 = NAM objective
+    const int64_t *max_intron; // per instance (quadratic NAM solver only)
+    int64_t *C_out;            // [total + n_inst]: instance i at off[i] + i, n + 1 entries, C[0] = 0
+    int32_t *trace_out;        // same layout, trace[0] = -1
 };
 
 // ---- quadratic ---------------------------------------------------------------------------------
@@ -83,19 +89,50 @@ __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
     const int64_t o = a.off[inst];
     const int n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
     const int cap = a.cap;
-    uint8_t *base = lds_raw + (size_t)wave * cap * 20;
+    const bool nam = a.nam != 0;
+    uint8_t *base = lds_raw + (size_t)wave * cap * (nam ? 24 : 20);
     double *sC = (double *)base;
     int32_t *sc = (int32_t *)(base + (size_t)cap * 8);
     int32_t *sd = sc + cap;
     int32_t *sp = sd + cap;
+    int32_t *sy = sp + cap; // NAM only
+    const int64_t oo = o + inst; // NAM outputs: n + 1 entries per instance
+    if (nam && lane == 0) { a.C_out[oo] = 0; a.trace_out[oo] = -1; }
     if (n <= 0) {
         if (lane == 0) { a.len[inst] = 0; a.value[inst] = -1.0; }
         return;
     }
-    for (int i = lane; i < n; i += 64) { sc[i] = a.c[o + i]; sd[i] = a.d[o + i]; }
+    for (int i = lane; i < n; i += 64) { sc[i] = a.c[o + i]; sd[i] = a.d[o + i]; if (nam) sy[i] = a.y[o + i]; }
     const int thr = a.thr;
+    const long long max_intron = nam ? a.max_intron[inst] : 0;
     for (int j = 0; j < n; j++) {
         const int cj = sc[j];
+        if (nam) {
+            // read_coverage (colinear_solver.py:169-272): T = C[j'] over d[j'] < c, I = C[j'] + (d - d[j']) over
+            // c <= d[j'] <= d, both only within max_intron on the genome; ties -> largest j'; C_a wins ties
+            const int dcur = sd[j];
+            const long long yj = sy[j];
+            Cand T = {0.0, -1, 0}, I = {0.0, -1, 0};
+            for (int jp = lane; jp < j; jp += 64) {
+                if (yj - (long long)sy[jp] >= max_intron) continue;
+                const int dj = sd[jp];
+                const double Cp = sC[jp];
+                if (dj < cj) { Cand t = {Cp, jp, 1}; T = better_hi(T, t); }
+                if (cj <= dj && dj <= dcur) { Cand t = {__dadd_rn(Cp, (double)(dcur - dj)), jp, 1}; I = better_hi(I, t); }
+            }
+            T = wave_reduce<true>(T);
+            I = wave_reduce<true>(I);
+            const double Ca = __dadd_rn((double)(dcur - cj + 1), T.has ? T.v : 0.0);
+            const double Cb = I.has ? I.v : 0.0;
+            if (lane == 0) {
+                const int jp = Ca >= Cb ? (T.has ? T.idx : -1) : (I.has ? I.idx : -1);
+                const double v = Ca >= Cb ? Ca : Cb;
+                sC[j] = v; sp[j] = jp;
+                a.C_out[oo + j + 1] = (int64_t)v;
+                a.trace_out[oo + j + 1] = jp < 0 ? 0 : jp + 1;
+            }
+            continue;
+        }
         const double vj = a.val[o + j];
         Cand T = {0.0, -1, 0}, I = {0.0, -1, 0};
         for (int jp = lane; jp < j; jp += 64) {
@@ -126,6 +163,7 @@ __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
     for (int i = lane; i < n; i += 64) { Cand t = {sC[i], i, 1}; B = better_lo(B, t); }
     B = wave_reduce<false>(B);
     if (lane == 0) {
+        if (nam) { a.len[inst] = n; a.value[inst] = B.v; return; }
         int len = 0;
         for (int j = B.idx; j >= 0; j = sp[j]) len++;
         int w = len;
@@ -149,7 +187,7 @@ __device__ __forceinline__ int first_greater(const int32_t *ld, int nleaf, int k
     return fallback ? nleaf - 1 : lo;
 }
 
-__global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
+template <bool NAM> __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
 {
     extern __shared__ uint8_t lds_raw[];
     const int lane = threadIdx.x;
@@ -159,7 +197,10 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
     const int64_t o = a.off[inst];
     const int n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
     if (n <= 0) {
-        if (lane == 0) { a.len[inst] = 0; a.value[inst] = -1.0; }
+        if (lane == 0) {
+            a.len[inst] = 0; a.value[inst] = -1.0;
+            if (NAM) { a.C_out[o + inst] = 0; a.trace_out[o + inst] = -1; }
+        }
         return;
     }
     // leaf count (colinear_solver.py:64-83): n+1 nodes padded up to a power of two
@@ -168,7 +209,11 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
     const int npad = nleaf - cnt;
     const int nchunk = (nleaf + 63) >> 6;
     // LDS: lC[nleaf] f64 | ld[nleaf] i32 | lj[nleaf] i32 | cmC[nchunk] f64 | cmJ[nchunk] i32
+    // NAM: the 8 bytes per leaf hold two int32 instead - the T tree's C and the I tree's C - d (all values are
+    // integers below 2^31, the host checks the coordinates), so both trees fit where the MAM solver keeps one
     double *lC = (double *)lds_raw;
+    int32_t *lTi = (int32_t *)lds_raw, *lIi = lTi + nleaf;
+    constexpr int32_t NEGI = (int32_t)0x80000000;
     int32_t *ld = (int32_t *)(lds_raw + (size_t)nleaf * 8);
     int32_t *lj = ld + nleaf;
     double *cmC = (double *)(lds_raw + (size_t)nleaf * 16);
@@ -214,9 +259,17 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
     // keys alias lC: read every d before lC is initialised
     for (int r = lane; r < n; r += 64) ld[1 + npad + r] = (int32_t)(uint32_t)(keys[r] >> 32);
     for (int i = lane; i <= npad; i += 64) ld[i] = -1;
-    for (int i = lane; i < nleaf; i += 64) lC[i] = NEG;
+    if (NAM) {
+        // ld was filled from the keys that alias this area: every lane is past those reads (one wave, in order)
+        for (int i = lane; i < nleaf; i += 64) { lTi[i] = NEGI; lIi[i] = NEGI; }
+    } else {
+        for (int i = lane; i < nleaf; i += 64) lC[i] = NEG;
+    }
     for (int i = lane; i < nchunk; i += 64) { cmC[i] = NEG; cmJ[i] = -0x7fffffff; }
-    if (lane == 0) { lC[0] = 0.0; cmC[0] = 0.0; cmJ[0] = -1; }
+    if (lane == 0) {
+        if (NAM) { lTi[0] = 0; lIi[0] = 0; } else lC[0] = 0.0;
+        cmC[0] = 0.0; cmJ[0] = -1;
+    }
     // ---- per-MAM query ranges (leaf keys never change) ----
     const int thr = a.thr;
     int bug = 0;
@@ -228,8 +281,8 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
         int plen = hi + ((fb && ld[hi] == c - 1) ? 1 : 0);
         if (plen <= 0) bug = 1; // the reference's "BUG" exit: cannot happen, leaf 0 has d = -1
         qT[j] = plen;
-        // I query [c, c-1+thr]
-        const int r = c - 1 + thr;
+        // I query [c, c-1+thr] (MAM, :437) or [c, d] (NAM, colinear_solver.py:137)
+        const int r = NAM ? gd[j] : c - 1 + thr;
         bool fbl, fbh;
         int lo = first_greater(ld, nleaf, c, true, fbl);
         int hi2 = first_greater(ld, nleaf, r, false, fbh);
@@ -253,7 +306,7 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
     for (int j = 0; j < n; j++) {
         const int plen = qT[j];
         const int b = qIlo[j], e = qIhi[j];
-        const double vj = gv[j];
+        const double vj = NAM ? (double)(gd[j] - gc[j] + 1) : gv[j];
         // T: lexicographic (C, j) max over leaves [0, plen)
         Cand T = {0.0, 0, 0};
         const int full = plen >> 6;
@@ -264,14 +317,24 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
         {
             int i = (full << 6) + lane;
             if (i < plen) {
-                double cv = lC[i];
-                if (cv != NEG) { Cand t = {cv, lj[i], 1}; T = better_hi(T, t); }
+                if (NAM) {
+                    int32_t ci = lTi[i];
+                    if (ci != NEGI) { Cand t = {(double)ci, lj[i], 1}; T = better_hi(T, t); }
+                } else {
+                    double cv = lC[i];
+                    if (cv != NEG) { Cand t = {cv, lj[i], 1}; T = better_hi(T, t); }
+                }
             }
         }
         Cand I = {0.0, 0, 0};
         for (int i = b + lane; i < e; i += 64) {
-            double cv = lC[i];
-            if (cv != NEG) { Cand t = {cv, lj[i], 1}; I = better_hi(I, t); }
+            if (NAM) {
+                int32_t ci = lIi[i];
+                if (ci != NEGI) { Cand t = {(double)ci, lj[i], 1}; I = better_hi(I, t); }
+            } else {
+                double cv = lC[i];
+                if (cv != NEG) { Cand t = {cv, lj[i], 1}; I = better_hi(I, t); }
+            }
         }
         T = wave_reduce<true>(T);
         I = wave_reduce<true>(I);
@@ -279,7 +342,13 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
         const double Ca = __dadd_rn(T.v, vj);
         double v = Ca;
         int jp = T.idx;
-        if (I.has) {
+        if (NAM) {
+            // C_b = I + d (:139); an I range without a processed leaf leaves the reference with -2^32 + d < C_a
+            if (I.has) {
+                double Cb = __dadd_rn(I.v, (double)gd[j]);
+                if (Cb > Ca) { v = Cb; jp = I.idx; }
+            }
+        } else if (I.has) {
             int jb = I.idx < 0 ? I.idx + n : I.idx; // Python negative indexing (:448-451)
             double pen = (gx[j] != gy[jb]) ? __dadd_rn((double)(gd[jb] - (gc[j] - 1)), 0.0001) : 0.0001;
             double Cb = __dsub_rn(__dadd_rn(I.v, vj), pen);
@@ -289,7 +358,8 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
             C[j + 1] = v;
             trace[j + 1] = (jp < 0 || v == 0.0) ? 0 : jp + 1;
             int leaf = leaf_of[j];
-            lC[leaf] = v;
+            if (NAM) { lTi[leaf] = (int32_t)v; lIi[leaf] = (int32_t)(v - (double)gd[j]); }
+            else lC[leaf] = v;
             int ch = leaf >> 6;
             double cv = cmC[ch];
             if (cv == NEG || v > cv || (v == cv && j > cmJ[ch])) { cmC[ch] = v; cmJ[ch] = j; }
@@ -299,6 +369,12 @@ __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs a)
     Cand B = {0.0, -1, 0};
     for (int i = lane; i <= n; i += 64) { Cand t = {C[i], i, 1}; B = better_lo(B, t); }
     B = wave_reduce<false>(B);
+    if (NAM) {
+        const int64_t oo = o + inst;
+        for (int i = lane; i <= n; i += 64) { a.C_out[oo + i] = (int64_t)C[i]; a.trace_out[oo + i] = i == 0 ? -1 : trace[i]; }
+        if (lane == 0) { a.len[inst] = n; a.value[inst] = B.v; }
+        return;
+    }
     if (lane == 0) {
         int len = 0;
         for (int i = B.idx; i > 0; i = trace[i]) len++;
@@ -317,7 +393,7 @@ constexpr int kLdsBudget = 160 * 1024;
 void ultra_chain_free(ultra_ctx *ctx)
 {
     ChainState &ch = ctx->ch;
-    DevBuf *bufs[] = {&ch.ioff, &ch.off, &ch.x, &ch.y, &ch.c, &ch.d, &ch.val, &ch.idx, &ch.len, &ch.value, &ch.work};
+    DevBuf *bufs[] = {&ch.ioff, &ch.off, &ch.x, &ch.y, &ch.c, &ch.d, &ch.val, &ch.idx, &ch.len, &ch.value, &ch.work, &ch.namC, &ch.namtrace, &ch.intron};
     for (DevBuf *b : bufs) b->release();
 }
 
@@ -329,8 +405,9 @@ void ultra_chain_free(ultra_ctx *ctx)
 int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, const int64_t *d_off, const int32_t *d_cnt,
                        const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
                        int32_t solver, int32_t overlap_small, int32_t overlap_large,
-                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out)
+                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out, const ultra_nam_chain *nam)
 {
+    const size_t qstride = nam ? 24 : 20; // LDS bytes per entry of the quadratic kernel
     if (solver < 0 || solver > 2) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: solver must be 0, 1 or 2");
     const int thr_s = overlap_small < 0 ? ctx->cfg.overlap_small : overlap_small;
     const int thr_l = overlap_large < 0 ? ctx->cfg.overlap_large : overlap_large;
@@ -339,15 +416,17 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     for (int32_t i = 0; i < n_inst; i++) {
         const int32_t n = h_cnt[i];
         if (n < 0) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: negative instance size");
-        bool use_tree = solver == 2 || (solver == 0 && n > ctx->cfg.chain_switch_n);
+        // MAM: n > 200 -> n log n (classify_read_with_mams.py:586); NAM: n >= 90 (align.py:448)
+        bool use_tree = solver == 2 || (solver == 0 && (nam ? n >= ctx->cfg.nam_switch_n : n > ctx->cfg.chain_switch_n));
         if (use_tree && n > 0) {
-            if (thr_l < 1) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: n log n solver needs overlap threshold >= 1");
+            if (!nam && thr_l < 1) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: n log n solver needs overlap threshold >= 1");
             tree.push_back(i); max_tree = std::max<int32_t>(max_tree, n);
         } else if (n <= kQuadSmall) small.push_back(i);
         else { big.push_back(i); max_big = std::max<int32_t>(max_big, n); }
     }
-    if ((size_t)max_big * 20 > (size_t)kLdsBudget)
-        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "chaining: quadratic solver limited to 8192 MAMs per instance");
+    if ((size_t)max_big * qstride > (size_t)kLdsBudget)
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, nam ? "chaining: quadratic solver limited to 6826 NAMs per instance"
+                                                        : "chaining: quadratic solver limited to 8192 MAMs per instance");
     int tree_leaves = 1;
     while (tree_leaves < max_tree + 1) tree_leaves <<= 1;
     size_t tree_lds = (size_t)tree_leaves * 16 + (size_t)((tree_leaves + 63) / 64) * 12 + 16;
@@ -385,15 +464,16 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     a.off = d_off; a.cnt = d_cnt; a.x = d_x; a.y = d_y; a.c = d_c; a.d = d_d;
     a.val = d_val; a.idx = d_idx; a.len = d_len; a.value = d_value;
     a.status = d_status;
+    if (nam) { a.nam = 1; a.max_intron = nam->d_max_intron; a.C_out = nam->d_C; a.trace_out = nam->d_trace; }
     if (!small.empty()) {
         a.thr = thr_s; a.list = d_list; a.nlist = (int32_t)small.size(); a.cap = kQuadSmall;
         int blocks = ((int)small.size() + 3) / 4;
-        hipLaunchKernelGGL(chain_quadratic, dim3(blocks), dim3(256), (size_t)4 * kQuadSmall * 20, s, a);
+        hipLaunchKernelGGL(chain_quadratic, dim3(blocks), dim3(256), (size_t)4 * kQuadSmall * qstride, s, a);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     if (!big.empty()) {
         a.thr = thr_s; a.list = d_list + small.size(); a.nlist = (int32_t)big.size(); a.cap = max_big;
-        size_t shmem = (size_t)max_big * 20;
+        size_t shmem = (size_t)max_big * qstride;
         if (shmem > 64 * 1024)
             ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_quadratic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(chain_quadratic, dim3((unsigned)big.size()), dim3(64), shmem, s, a);
@@ -402,9 +482,11 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     if (!tree.empty()) {
         a.thr = thr_l; a.list = d_list + small.size() + big.size(); a.nlist = (int32_t)tree.size(); a.cap = tree_leaves;
         a.work = ch.work.as<uint8_t>(); a.work_off = d_workoff;
+        const void *fn = nam ? (const void *)chain_nlogn<true> : (const void *)chain_nlogn<false>;
         if (tree_lds > 64 * 1024)
-            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_nlogn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
-        hipLaunchKernelGGL(chain_nlogn, dim3((unsigned)tree.size()), dim3(64), tree_lds, s, a);
+            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
+        if (nam) hipLaunchKernelGGL(chain_nlogn<true>, dim3((unsigned)tree.size()), dim3(64), tree_lds, s, a);
+        else hipLaunchKernelGGL(chain_nlogn<false>, dim3((unsigned)tree.size()), dim3(64), tree_lds, s, a);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     return ULTRA_OK;
@@ -449,7 +531,7 @@ extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int6
     int32_t *d_status = nullptr;
     int rc = ultra_chain_launch(ctx, n_inst, h_cnt.data(), ch.ioff.as<int64_t>(), nullptr, ch.x.as<int32_t>(), ch.y.as<int32_t>(),
                                 ch.c.as<int32_t>(), ch.d.as<int32_t>(), ch.val.as<double>(), solver, overlap_small, overlap_large,
-                                ch.idx.as<int32_t>(), ch.len.as<int32_t>(), ch.value.as<double>(), &d_status);
+                                ch.idx.as<int32_t>(), ch.len.as<int32_t>(), ch.value.as<double>(), &d_status, nullptr);
     if (rc != ULTRA_OK) { (void)hipStreamSynchronize(s); return rc; }
     int32_t status = 0;
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(chain_len, ch.len.p, ni * 4, hipMemcpyDeviceToHost, s));
@@ -460,5 +542,74 @@ extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int6
     if (status != 0)
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: an instance reached the reference's 'BUG' state "
                                             "(empty range-query node set); check that c <= d for every MAM");
+    return ULTRA_OK;
+}
+
+// NAM chaining, SURVEY.md section 8 row f1.  Replaces colinear_solver.read_coverage (modules/colinear_solver.py:169-272)
+// and n_logn_read_coverage (:85-167) as align.py:448-453 calls them, for a batch of (read, chromosome, strand) instances.
+extern "C" int ultra_chain_nams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
+                                      const int32_t *y, const int32_t *c, const int32_t *d,
+                                      const int64_t *max_intron, int32_t solver,
+                                      int64_t *C, int32_t *trace, int64_t *value)
+{
+    if (!ctx) return ULTRA_E_ARG;
+    if (n_inst < 0 || (n_inst > 0 && (!inst_off || !C || !trace || !value)))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: null pointer or negative instance count");
+    if (solver < 0 || solver > 2) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: solver must be 0, 1 or 2");
+    if (n_inst == 0) return ULTRA_OK;
+    const int64_t total = inst_off[n_inst];
+    if (inst_off[0] != 0 || total < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: inst_off must start at 0");
+    if (total > 0 && (!c || !d)) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: null NAM array");
+    std::vector<int32_t> h_cnt((size_t)n_inst);
+    bool any_quadratic = false;
+    for (int32_t i = 0; i < n_inst; i++) {
+        int64_t n = inst_off[i + 1] - inst_off[i];
+        if (n < 0 || n > 0x7fffffff) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: inst_off must be non-decreasing");
+        h_cnt[(size_t)i] = (int32_t)n;
+        if (n > 0 && (solver == 1 || (solver == 0 && n < ctx->cfg.nam_switch_n))) any_quadratic = true;
+    }
+    if (any_quadratic && (!y || !max_intron))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: the quadratic solver needs y and max_intron");
+    // the kernels keep C and C - d as int32 / exact doubles: read coordinates must be sane
+    for (int64_t i = 0; i < total; i++)
+        if (c[i] < 0 || d[i] < c[i] || d[i] >= (1 << 30))
+            return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: NAM " + std::to_string(i) + " has read interval [" +
+                                                    std::to_string(c[i]) + ", " + std::to_string(d[i]) + "]; need 0 <= c <= d < 2^30");
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ChainState &ch = ctx->ch;
+    hipStream_t s = ctx->stream;
+    const size_t nt = (size_t)std::max<int64_t>(total, 1), ni = (size_t)n_inst;
+    ULTRA_HIP_CHECK(ctx, ch.ioff.ensure((ni + 1) * 8));
+    ULTRA_HIP_CHECK(ctx, ch.y.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.c.ensure(nt * 4)); ULTRA_HIP_CHECK(ctx, ch.d.ensure(nt * 4));
+    ULTRA_HIP_CHECK(ctx, ch.len.ensure(ni * 4 + 16)); ULTRA_HIP_CHECK(ctx, ch.value.ensure(ni * 8));
+    ULTRA_HIP_CHECK(ctx, ch.namC.ensure((nt + ni) * 8)); ULTRA_HIP_CHECK(ctx, ch.namtrace.ensure((nt + ni) * 4));
+    ULTRA_HIP_CHECK(ctx, ch.intron.ensure(ni * 8));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.ioff.p, inst_off, (ni + 1) * 8, hipMemcpyHostToDevice, s));
+    if (total > 0) {
+        if (y) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.y.p, y, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.c.p, c, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.d.p, d, nt * 4, hipMemcpyHostToDevice, s));
+    }
+    if (max_intron) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(ch.intron.p, max_intron, ni * 8, hipMemcpyHostToDevice, s));
+    else ULTRA_HIP_CHECK(ctx, hipMemsetAsync(ch.intron.p, 0, ni * 8, s));
+    ultra_nam_chain nam = {ch.intron.as<int64_t>(), ch.namC.as<int64_t>(), ch.namtrace.as<int32_t>()};
+    int32_t *d_status = nullptr;
+    // x and val are not read in NAM mode (the n log n kernel forms pointers from them only)
+    int rc = ultra_chain_launch(ctx, n_inst, h_cnt.data(), ch.ioff.as<int64_t>(), nullptr, ch.y.as<int32_t>(), ch.y.as<int32_t>(),
+                                ch.c.as<int32_t>(), ch.d.as<int32_t>(), nullptr, solver, -1, -1,
+                                nullptr, ch.len.as<int32_t>(), ch.value.as<double>(), &d_status, &nam);
+    if (rc != ULTRA_OK) { (void)hipStreamSynchronize(s); return rc; }
+    int32_t status = 0;
+    std::vector<double> h_value(ni);
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(C, ch.namC.p, (size_t)(total + n_inst) * 8, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(trace, ch.namtrace.p, (size_t)(total + n_inst) * 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_value.data(), ch.value.p, ni * 8, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (status != 0)
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_nams_batch: an instance reached the reference's 'BUG' state");
+    // value = max(C) (colinear_solver.py:159, :245); an instance without NAMs has C = [0]
+    for (size_t i = 0; i < ni; i++) value[i] = h_cnt[i] > 0 ? (int64_t)h_value[i] : 0;
     return ULTRA_OK;
 }

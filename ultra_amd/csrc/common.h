@@ -76,7 +76,7 @@ struct MyersState {
 };
 
 struct ChainState {
-    DevBuf ioff, off, x, y, c, d, val, idx, len, value, work;
+    DevBuf ioff, off, x, y, c, d, val, idx, len, value, work, namC, namtrace, intron;
     std::vector<int32_t> h_list;     // kept alive until the stream has consumed them
     std::vector<int64_t> h_workoff;
 };
@@ -147,6 +147,13 @@ static inline int ultra_fail(ultra_ctx *ctx, int code, const std::string &msg)
     return code;
 }
 
+// NAM mode of ultra_chain_launch: per-instance intron limits in, DP vectors out (device pointers)
+struct ultra_nam_chain {
+    const int64_t *d_max_intron;
+    int64_t *d_C;
+    int32_t *d_trace;
+};
+
 int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
                            const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                            const int32_t *k);
@@ -154,7 +161,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops);
 int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, const int64_t *d_off, const int32_t *d_cnt,
                        const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
                        int32_t solver, int32_t overlap_small, int32_t overlap_large,
-                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out);
+                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out,
+                       const ultra_nam_chain *nam = nullptr);
 // exclusive scan of n 64-bit values on ctx->stream (tmp: scratch, grown as needed)
 hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp);
 void ultra_myers_free(ultra_ctx *ctx);

@@ -20,7 +20,7 @@ _ERR_NAMES = {-1: "ULTRA_E_ARG", -2: "ULTRA_E_HIP", -3: "ULTRA_E_CAPACITY", -4: 
 EXPORTS = [
     "ultra_cfg_default", "ultra_ctx_create", "ultra_ctx_destroy", "ultra_last_error", "ultra_device_count",
     "ultra_device_info", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
-    "ultra_myers_last_timing", "ultra_myers_class_timing", "ultra_chain_mams_batch",
+    "ultra_myers_last_timing", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
 ]
 
@@ -33,7 +33,7 @@ class UltraError(RuntimeError):
 
 class Cfg(C.Structure):
     _fields_ = [("chain_switch_n", C.c_int32), ("overlap_small", C.c_int32), ("overlap_large", C.c_int32),
-                ("loc_slots", C.c_int32), ("banded_traceback", C.c_int32)]
+                ("loc_slots", C.c_int32), ("banded_traceback", C.c_int32), ("nam_switch_n", C.c_int32)]
 
 
 _I32P, _I64P, _U8P, _F64P = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
@@ -90,6 +90,7 @@ def load():
     lib.ultra_myers_class_timing.argtypes = [vp, C.c_int32, i32p, i32p, f64p, C.POINTER(C.c_float), i32p]
     lib.ultra_chain_mams_batch.argtypes = [vp, C.c_int32, i64p, i32p, i32p, i32p, i32p, f64p, C.c_int32, C.c_int32,
                                            C.c_int32, i32p, i32p, f64p]
+    lib.ultra_chain_nams_batch.argtypes = [vp, C.c_int32, i64p, i32p, i32p, i32p, i64p, C.c_int32, i64p, i32p, i64p]
     lib.ultra_mam_batch.argtypes = [vp, C.POINTER(MamInput), C.c_double, C.POINTER(MamOutput)]
     lib.ultra_mam_stage.argtypes = [vp, C.POINTER(MamInput)]
     lib.ultra_mam_run.argtypes = [vp, C.c_double]
@@ -308,6 +309,22 @@ class Context(object):
                                                     _ptr(val, C.c_double), solver, overlap_small, overlap_large,
                                                     _ptr(idx, C.c_int32), _ptr(ln, C.c_int32), _ptr(value, C.c_double)))
         return idx, ln[:ni], value[:ni]
+
+    def chain_nams_batch(self, inst_off, y, c, d, max_intron=None, solver=0):
+        """NAM chaining of a batch; returns (C, trace, value): the DP vectors (n + 1 entries per instance,
+        instance i at inst_off[i] + i) and max(C) per instance."""
+        inst_off = _arr(inst_off, np.int64)
+        c, d = _arr(c, np.int32), _arr(d, np.int32)
+        y = None if y is None else _arr(y, np.int32)
+        ni = len(inst_off) - 1
+        mi = None if max_intron is None else _arr(np.broadcast_to(np.asarray(max_intron, np.int64), (ni,)), np.int64)
+        Cv = np.zeros(len(c) + max(ni, 1), np.int64); tr = np.zeros(len(c) + max(ni, 1), np.int32)
+        value = np.zeros(max(ni, 1), np.int64)
+        self._check(self.lib.ultra_chain_nams_batch(self._h, ni, _ptr(inst_off, C.c_int64),
+                                                    None if y is None else _ptr(y, C.c_int32), _ptr(c, C.c_int32),
+                                                    _ptr(d, C.c_int32), None if mi is None else _ptr(mi, C.c_int64), solver,
+                                                    _ptr(Cv, C.c_int64), _ptr(tr, C.c_int32), _ptr(value, C.c_int64)))
+        return Cv[:len(c) + ni], tr[:len(c) + ni], value[:ni]
 
 
 _default_ctx = None
