@@ -12,8 +12,10 @@ exist offline.  Reads are independent, so with N > 1 every rank runs its own sha
 data-path collective; torch.distributed is used for the barrier and the max-over-ranks time only).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (Myers forward class with the most time): integer-VALU bound,
-                achieved = 0.75 int32-op/cell * cells / HIP-event time of that kernel
+  roofline      the Myers forward pass (one kernel template, launched once per register bucket, the launches of
+                a step running concurrently): integer-VALU bound, achieved = 0.75 int32-op/cell * forward cells
+                of the step / HIP-event time from the first launch's start to the last one's end;
+                `largest_instantiation` = the same for the single biggest launch (shares the chip meanwhile)
   cpu_baseline  the CPU oracle (oracle/, "port") timed on a bounded sample on the host cores
 """
 import argparse
@@ -152,7 +154,7 @@ def main():
     for _ in range(args.warmup):
         run_all()
     class_ms = {}
-    fwd_ms = rev_ms = tb_ms = all_ms = 0.0
+    fwd_ms = rev_ms = tb_ms = all_ms = fwdk_ms = 0.0
     build_ms = chain_ms = gather_ms = 0.0
     barrier()
     t0 = time.perf_counter()
@@ -160,7 +162,7 @@ def main():
         run_all()
         for c in ctxs:
             _, ms = c.myers_timing()
-            fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]
+            fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]; fwdk_ms += ms[4]
             mm = c.mam_timing()
             build_ms += mm[0]; chain_ms += mm[1]; gather_ms += mm[2]
             for key, (cc, t) in c.myers_class_timing().items():
@@ -208,22 +210,31 @@ def main():
             dur = ms / launches * 1e-3
             achieved = ops_per_launch / dur * 1e-12
             kname = "myers_mega<0, %d>" % G   # forward pass (MODE 0) of register bucket G
-            traffic = None  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (profiles/)
+            # HBM bytes from the committed rocprofv3 --pmc passes of this same command (profiles/)
+            traffic = fam_traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
                     rec = json.load(open(pmc))
                     if rec.get("dominant_kernel") == kname:
                         traffic = rec.get("hbm_bytes_per_launch")
+                    fam_traffic = rec.get("forward_family", {}).get("hbm_bytes_per_step")
                 except Exception:
-                    traffic = None
-            roof = {"bound": "valu_int32", "kernel": kname, "achieved": achieved,
-                    "peak": peak_ops * 1e-12, "unit": "Tops/s", "frac": achieved / (peak_ops * 1e-12),
-                    "traffic": traffic, "cells_per_launch": c / launches, "avg_launch_ms": ms / launches,
+                    traffic = fam_traffic = None
+            # The forward pass is ONE kernel template instantiated per register bucket; the (up to 5) instantiations
+            # of a step are launched together on 4 streams and share the CUs, so the duration of a single one says
+            # how long it shared the chip, not how fast it is.  The roofline is therefore taken over the family:
+            # all forward cells of the step / (first launch start -> last launch end, HIP events on those streams).
+            # The largest single instantiation, whose avg duration is the one rocprofv3 --stats lists, is kept below.
+            fam_ms = fwdk_ms / K / max(1, args.contexts)
+            fam_ach = OPS_PER_CELL * (cells_all / world) / (fam_ms * 1e-3) * 1e-12 if fam_ms > 0 else 0.0
+            roof = {"bound": "valu_int32", "kernel": "myers_mega<0, 0..4> (forward pass: concurrent launches, one per register bucket)",
+                    "achieved": fam_ach, "peak": peak_ops * 1e-12, "unit": "Tops/s", "frac": fam_ach / (peak_ops * 1e-12),
+                    "traffic": fam_traffic, "cells_per_launch": cells_all / world, "avg_launch_ms": fam_ms,
                     "ops_per_cell": OPS_PER_CELL,
-                    # all forward kernels together (they run concurrently on 4 streams; includes the CSR scan and the exact re-run)
-                    "forward_pass_all_buckets": {"cells_per_step": cells_all / world, "ms_per_step": fwd_ms / K / max(1, args.contexts),
-                                                 "frac": (OPS_PER_CELL * cells_all / world / (fwd_ms / K / max(1, args.contexts) * 1e-3)) / peak_ops if fwd_ms > 0 else None},
+                    "largest_instantiation": {"kernel": kname, "achieved": achieved, "frac": achieved / (peak_ops * 1e-12),
+                                              "traffic": traffic, "cells_per_launch": c / launches, "avg_launch_ms": ms / launches,
+                                              "note": "runs concurrently with the other buckets' launches"},
                     "hbm": {"algorithmic_bytes_per_step": batch.algorithmic_bytes, "achieved_GBs":
                             batch.algorithmic_bytes / (all_ms / K * 1e-3) * 1e-9 if all_ms > 0 else None,
                             "peak_GBs": HBM_PEAK_GBS}}

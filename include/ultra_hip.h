@@ -103,9 +103,11 @@ int ultra_myers_fetch(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
                       int32_t *loc_start, int32_t *loc_end, int64_t loc_cap, int64_t *loc_need,
                       int32_t *first_ins);
 /* Forward-pass cell count (sum of q_len*t_len) and device milliseconds of the last _run, split by
- * stage: [0] forward (distance + end positions), [1] reverse (start positions), [2] traceback,
- * [3] everything (first launch to last completion).  Measured with HIP events on the ctx stream. */
-int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[4]);
+ * stage: [0] forward (distance + end positions, incl. the location scan and the exact re-run), [1] reverse
+ * (start positions), [2] traceback, [3] everything (first launch to last completion), [4] the forward
+ * kernels alone (the concurrent myers_mega<FWD, bucket> launches, first start to last end).  Measured with
+ * HIP events on the streams the kernels are launched on. */
+int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[5]);
 /* Per register bucket of the last _run (a bucket = one forward kernel, myers_mega<FWD, bucket>, covering
  * the size classes up to W 64-row words per lane; bucket 3 = multi-lane classes for queries > 512):
  * G[i] = bucket id, W[i] = its widest class, forward-pass cells of its pairs and device milliseconds

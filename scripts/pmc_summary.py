@@ -48,11 +48,18 @@ def main():
     out["dominant_avg_us"] = d["avg_us"]
     out["hbm_bytes_per_launch"] = int(((d["fetch_kb_raw"] or 0) * 2 + (d["write_kb"] or 0)) * 1024)
     out["hbm_bytes_per_launch_raw_counters"] = int(((d["fetch_kb_raw"] or 0) + (d["write_kb"] or 0)) * 1024)
+    # the forward pass = the myers_mega<0, bucket> launches of one step, which run concurrently (one per lane)
+    fam = [k for k in out["kernels"] if k["kernel"].startswith("myers_mega<0,")]
+    out["forward_family"] = {
+        "kernels": [k["kernel"] for k in fam],
+        "hbm_bytes_per_step": int(sum(((k["fetch_kb_raw"] or 0) * 2 + (k["write_kb"] or 0)) * 1024 for k in fam)),
+        "longest_avg_us": max([k["avg_us"] for k in fam] or [0.0]),
+        "sum_avg_us": sum(k["avg_us"] for k in fam)}
     with open(os.path.join(ROOT, "profiles", "%s_summary.json" % tag), "w") as fh:
         json.dump(out, fh, indent=1)
     with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as fh:
         json.dump({k: out[k] for k in ("tag", "dominant_kernel", "dominant_avg_us", "hbm_bytes_per_launch",
-                                      "hbm_bytes_per_launch_raw_counters")}, fh, indent=1)
+                                      "hbm_bytes_per_launch_raw_counters", "forward_family")}, fh, indent=1)
     print(dominant, d["avg_us"], out["hbm_bytes_per_launch"])
 
 

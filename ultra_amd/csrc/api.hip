@@ -90,11 +90,11 @@ int ultra_myers_run(ultra_ctx *ctx)
     return ultra_myers_run_impl(ctx, false);
 }
 
-int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[4])
+int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[5])
 {
     if (!ctx || !ctx->my.ran) return ULTRA_E_STATE;
     if (cells) *cells = ctx->my.cells;
-    if (ms) for (int i = 0; i < 4; i++) ms[i] = ctx->my.ms[i];
+    if (ms) for (int i = 0; i < 5; i++) ms[i] = ctx->my.ms[i];
     return ULTRA_OK;
 }
 

@@ -68,7 +68,7 @@ struct MyersState {
     std::vector<int64_t> h_qoff, h_toff;
     std::vector<int32_t> h_qlen, h_tlen, h_k;
     double cells = 0;
-    float ms[4] = {0, 0, 0, 0};
+    float ms[5] = {0, 0, 0, 0, 0};
     int64_t total_loc = 0, total_hit = 0;
     DevBuf seq, rseq, qoff, qlen, toff, tlen, k, ed, nloc, slots, packed, scanned, blocksum, locoff, hitoff,
         locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2;

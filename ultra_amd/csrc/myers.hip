@@ -1062,6 +1062,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev1, cs));
     }
     ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[4], s)); // all forward launches done
     // ---- CSR offsets ----
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bounds.as<int64_t>() + 63, 0, 8, s));
     hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n, a.slot_cap, st.bounds.as<int64_t>() + 63);
@@ -1283,6 +1284,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[1], st.ev[1], st.ev[2]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[2], st.ev[2], st.ev[3]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[3], st.ev[0], st.ev[3]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[4], st.ev[0], st.ev[4]));
     for (auto &bk : st.buckets) { bk.fwd_ms = 0; if (bk.n_fwd > 0) ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&bk.fwd_ms, bk.ev0, bk.ev1)); }
     st.ran = true;
     return ULTRA_OK;

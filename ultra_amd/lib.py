@@ -206,9 +206,9 @@ class Context(object):
 
     def myers_timing(self):
         cells = C.c_double()
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 5)()
         self._check(self.lib.ultra_myers_last_timing(self._h, C.byref(cells), ms))
-        return cells.value, [ms[i] for i in range(4)]
+        return cells.value, [ms[i] for i in range(5)]
 
     def myers_class_timing(self):
         """{(G, W): (cells, forward_ms)} of the last run."""
