@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <string.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -99,22 +100,35 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p)
 
 // One 64-row word, one column (Hyyro 2003 formulation of Myers 1999).  hp/hm = horizontal
 // carry into the word's top row (+1 / -1), updated to the carry out of its bottom row.
+// Written on 32-bit halves: gfx950 has a three-input bitwise op (v_bitop3_b32, truth table in the
+// immediate: a = 0xF0, b = 0xCC, c = 0xAA), v_lshl_or_b32 and v_alignbit_b32, so a word costs
+// 23 VALU instructions instead of the ~37 the 64-bit formulation compiles to.
+template <int TT> __device__ __forceinline__ uint32_t bop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 __device__ __forceinline__ void word_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t &hp, uint32_t &hm, uint64_t &Ph0)
 {
-    uint64_t Xv = Eq | Mv;
-    Eq |= (uint64_t)hm;
-    uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-    uint64_t u = Xh | Pv;
-    uint64_t Ph = (u & Mv) | ~u; // = Mv | ~(Xh | Pv)
-    uint64_t Mh = Pv & Xh;
-    uint32_t hpo = (uint32_t)(Ph >> 63), hmo = (uint32_t)(Mh >> 63);
-    Ph0 = Ph; // bit i: D[i][j] - D[i][j-1] == +1
-    Ph = (Ph << 1) | (uint64_t)hp;
-    Mh = (Mh << 1) | (uint64_t)hm;
-    uint64_t w = Xv | Ph;
-    Pv = (w & Mh) | ~w; // = Mh | ~(Xv | Ph)
-    Mv = Ph & Xv;
-    hp = hpo; hm = hmo;
+    const uint32_t pvl = (uint32_t)Pv, pvh = (uint32_t)(Pv >> 32), mvl = (uint32_t)Mv, mvh = (uint32_t)(Mv >> 32);
+    const uint32_t eqh = (uint32_t)(Eq >> 32);
+    uint32_t eql = (uint32_t)Eq;
+    const uint32_t xvl = eql | mvl, xvh = eqh | mvh;             // Xv = Eq | Mv
+    eql |= hm;                                                   // Eq |= (hin < 0)
+    const uint64_t sum = pack64(eql & pvl, eqh & pvh) + Pv;      // (Eq & Pv) + Pv: the one 64-bit carry chain
+    const uint32_t xhl = bop3<0xBE>((uint32_t)sum, pvl, eql);    // Xh = (sum ^ Pv) | Eq
+    const uint32_t xhh = bop3<0xBE>((uint32_t)(sum >> 32), pvh, eqh);
+    const uint32_t phl = bop3<0xF1>(mvl, xhl, pvl);              // Ph = Mv | ~(Xh | Pv)
+    const uint32_t phh = bop3<0xF1>(mvh, xhh, pvh);
+    const uint32_t mhl = pvl & xhl, mhh = pvh & xhh;             // Mh = Pv & Xh
+    Ph0 = pack64(phl, phh); // bit i: D[i][j] - D[i][j-1] == +1
+    const uint32_t psl = (phl << 1) | hp;                        // Ph = (Ph << 1) | (hin > 0)
+    const uint32_t psh = __builtin_amdgcn_alignbit(phh, phl, 31);
+    const uint32_t msl = (mhl << 1) | hm;                        // Mh = (Mh << 1) | (hin < 0)
+    const uint32_t msh = __builtin_amdgcn_alignbit(mhh, mhl, 31);
+    hp = phh >> 31; hm = mhh >> 31;
+    Pv = pack64(bop3<0xF1>(msl, xvl, psl), bop3<0xF1>(msh, xvh, psh)); // Pv' = Mh | ~(Xv | Ph)
+    Mv = pack64(psl & xvl, psh & xvh);                                 // Mv' = Ph & Xv
 }
 
 __device__ __forceinline__ uint64_t pad_mask(int pad, int blk) // bits of word blk whose global row index < pad
@@ -235,12 +249,16 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
         int32_t score = it.m;
         int32_t best = 0x3fffffff, cnt = 0, lim = it.k, last = -1;
         int32_t *out = nullptr; int32_t out_cap = 0;
-        if (MODE == MODE_FWD) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
+        if (MODE == MODE_FWD && it.valid) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
         if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
         ulonglong2 *tT = nullptr;
         if (MODE == MODE_NW) tT = a.tr + gwave * a.region + lane;
         const int n = it.valid ? it.n : 0;
         const int nmax = wave_max_i32(n);
+        // Columns every valid lane has (the pairs of a work item are sorted by target length, so this is nearly
+        // all of them): run without per-lane bounds tests.  Lanes without a pair tag along on the arena's first
+        // bytes with out_cap = 0; the NW pass stores every column, so it keeps the tested loop throughout.
+        const int nfast = MODE == MODE_NW ? 0 : (min(-wave_max_i32(it.valid ? -n : -0x7fffffff), nmax) & ~15);
         // Eight columns per target chunk.  The chunks are double-buffered (the load of the next one is
         // issued a whole block of columns before its first use) and the match words of column j+1 are
         // read from LDS while column j is computed.
@@ -250,14 +268,15 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
 #pragma unroll
             for (int b = 0; b < W; b++) eq[b] = pe[b * 64];
         };
-        auto block8 = [&](uint64_t chunk, int j0) {
+        auto block8 = [&](uint64_t chunk, int j0, auto tested) {
+            constexpr bool TESTED = decltype(tested)::value;
             uint64_t eq[W], eqn[W];
-            read_eq(eq, chunk, 0, j0 < n);
+            read_eq(eq, chunk, 0, !TESTED || j0 < n);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int j = j0 + u;
-                if (u < 7) read_eq(eqn, chunk, u + 1, j + 1 < n);
-                if (j < n) {
+                if (u < 7) read_eq(eqn, chunk, u + 1, !TESTED || j + 1 < n);
+                if (!TESTED || j < n) {
                     uint32_t hp = top_hp, hm = 0;
 #pragma unroll
                     for (int b = 0; b < W; b++) {
@@ -283,12 +302,19 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
                 for (int b = 0; b < W; b++) eq[b] = eqn[b];
             }
         };
-        uint64_t ca = (n > 0) ? load8(it.t) : 0, cb = 0;
-        for (int j0 = 0; j0 < nmax; j0 += 16) {
+        uint64_t ca = load8(it.t), cb = 0;
+        int j0 = 0;
+        for (; j0 < nfast; j0 += 16) {
+            cb = load8(it.t + j0 + 8);
+            block8(ca, j0, std::false_type{});
+            ca = load8(it.t + j0 + 16); // at most 8 bytes past the slice: the arena is padded
+            block8(cb, j0 + 8, std::false_type{});
+        }
+        for (; j0 < nmax; j0 += 16) {
             if (j0 + 8 < n) cb = load8(it.t + j0 + 8);
-            block8(ca, j0);
+            block8(ca, j0, std::true_type{});
             if (j0 + 16 < n) ca = load8(it.t + j0 + 16);
-            if (j0 + 8 < nmax) block8(cb, j0 + 8);
+            if (j0 + 8 < nmax) block8(cb, j0 + 8, std::true_type{});
         }
         if (MODE == MODE_FWD) {
             if (it.valid) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
