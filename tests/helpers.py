@@ -2,13 +2,14 @@
 import numpy as np
 
 
-def mutate(rng, s, rate):
+def mutate(rng, s, rate, mix=(0.5, 0.3, 0.2)):
+    """mix = shares of (deleted, substituted, inserted-after) positions among the erroneous ones."""
     out = []
     for ch in s:
         r = rng.rand()
-        if r < rate * 0.5:
+        if r < rate * mix[0]:
             continue
-        if r < rate * 0.8:
+        if r < rate * (mix[0] + mix[1]):
             out.append("ACGT"[rng.randint(0, 4)])
         elif r < rate:
             out.append(ch)
@@ -23,8 +24,9 @@ def rand_seq(rng, n, alpha="ACGT"):
 
 
 def make_pairs(rng, n_pairs, qlen_range, tlen_range, planted=0.5, rates=(0.0, 0.02, 0.07, 0.15, 0.3),
-               alpha="ACGT", kmode="ref"):
-    """Returns (arena uint8, q_off, q_len, t_off, t_len, k) with half the queries planted in the target."""
+               alpha="ACGT", kmode="ref", mix=(0.5, 0.3, 0.2), block=0):
+    """Returns (arena uint8, q_off, q_len, t_off, t_len, k) with half the queries planted in the target.
+    block > 0: a planted query also gets one contiguous gap of up to `block` bases (cut out or spliced in)."""
     chunks, size = [], 0
     q_off, q_len, t_off, t_len, ks = [], [], [], [], []
     for _ in range(n_pairs):
@@ -33,7 +35,11 @@ def make_pairs(rng, n_pairs, qlen_range, tlen_range, planted=0.5, rates=(0.0, 0.
         t = rand_seq(rng, n, alpha)
         if rng.rand() < planted and n > m:
             a = int(rng.randint(0, n - m + 1))
-            q = mutate(rng, t[a:a + m], rates[int(rng.randint(0, len(rates)))]) or "A"
+            q = mutate(rng, t[a:a + m], rates[int(rng.randint(0, len(rates)))], mix) or "A"
+            if block and len(q) > 4:
+                g = int(rng.randint(1, block + 1)); at = int(rng.randint(1, len(q) - 1))
+                q = (q[:at] + q[at + g:]) if rng.rand() < 0.5 else (q[:at] + rand_seq(rng, g, alpha) + q[at:])
+                q = q or "A"
         else:
             q = rand_seq(rng, m, alpha)
         if kmode == "ref":

@@ -109,19 +109,19 @@ def test_round_trip_property_at_scale(ctx):
 
 def test_banded_and_full_height_traceback_agree(ctx):
     """The banded traceback (default) and the full-height one (cfg banded_traceback=0, also the
-    fallback for distances > 254) give the same insertion counts; both equal the oracle."""
+    fallback for distances > 502) give the same insertion counts; both equal the oracle."""
     from ultra_amd import lib
     rng = np.random.RandomState(11)
     full = lib.Context(0, cfg={"banded_traceback": 0})
     try:
         for qr, tr, n, rates in [((9, 300), (100, 900), 1500, (0.0, 0.05, 0.2, 0.35)),
                                  ((300, 1400), (400, 2000), 200, (0.02, 0.1, 0.2)),
-                                 ((700, 1600), (900, 2400), 60, (0.3, 0.36))]:   # distances beyond every band class
+                                 ((1300, 1900), (1500, 2600), 60, (0.3, 0.36))]:   # distances beyond every band class
             pairs = helpers.make_pairs(rng, n, qr, tr, kmode="ref", planted=0.9, rates=rates)
             a = _check(ctx, pairs)
             b = _check(full, pairs)
             assert np.array_equal(a["first_ins"], b["first_ins"])
-            assert (a["ed"] > 254).any() or qr[0] < 700
+            assert (a["ed"] > 502).any() or qr[0] < 1300
     finally:
         full.close()
 
@@ -129,3 +129,17 @@ def test_banded_and_full_height_traceback_agree(ctx):
 def test_banded_traceback_wide_alphabet(ctx):
     rng = np.random.RandomState(12)
     _check(ctx, helpers.make_pairs(rng, 600, (9, 400), (100, 900), kmode="ref", planted=0.9, alpha="ACGTNRYKMSWacg"))
+
+
+@pytest.mark.parametrize("mix", [(1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.45, 0.1, 0.45), (0.5, 0.3, 0.2)])
+def test_banded_traceback_skewed_paths(ctx, mix):
+    """The band is shifted per pair towards the diagonals its path can reach (end diagonal m - L): deletion-only,
+    insertion-only and long contiguous gaps put the path far from the main diagonal, and the rates make the
+    distances straddle every band-class limit (54, 118, 246, 502)."""
+    rng = np.random.RandomState(13 + int(mix[0] * 10) + int(mix[2] * 100))
+    for qr, tr, n, rates, block in [((9, 260), (100, 900), 1200, (0.05, 0.2, 0.3, 0.38), 0),
+                                    ((100, 400), (300, 1000), 500, (0.1, 0.2, 0.3), 60),
+                                    ((250, 800), (500, 1600), 250, (0.08, 0.16, 0.3), 120),
+                                    ((600, 1500), (900, 2400), 80, (0.08, 0.17, 0.33), 200)]:
+        got = _check(ctx, helpers.make_pairs(rng, n, qr, tr, kmode="ref", planted=0.9, rates=rates, mix=mix, block=block))
+        assert (got["ed"] > 54).any()

@@ -501,7 +501,8 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
 // take D0 >> 1), which makes the cost per column independent of the query length, and the stored
 // traceback state {Pv, Ph} is WB words per column instead of ceil(m/64).  No Peq table: the window's
 // match vector is rebuilt from NP bit-planes of the query codes that slide with the window.
-// Window of column c: bit b <-> query row c - TOP + b, TOP = 32*WB - 1; needs ed <= 32*WB - 2.
+// Window of column c: bit b <-> query row c - TOP + off + b, TOP = 32*WB - 1, off = per-pair shift towards the
+// diagonals the path can reach (below); needs ed <= 64*WB - 10.
 //
 // Traceback state never goes through HBM as whole columns: the forward sweep only leaves a
 // checkpoint (Pv, Mv, bit-planes) every K columns; the walk then goes through the chunks backwards,
@@ -523,23 +524,33 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
     ulonglong2 *col = band_lds + lane; // (column k of the chunk, word w) at col[(k * WB + w) * 64]
     for (int64_t base = gwave * 64; base < n_items; base += nwaves * 64) {
         const bool valid = base + lane < n_items;
-        int p = 0, m = 0, L = 0;
+        int p = 0, m = 0, L = 0, ed = 0;
         const uint8_t *q = a.seq, *t = a.seq;
         if (valid) {
             p = items[base + lane];
             m = a.q_len[p];
+            ed = a.ed[p];
             const int64_t lo = a.loc_off[p];
             const int s0 = a.loc_start[lo];
             L = a.loc_end[lo] - s0 + 1;
             q = a.seq + a.q_off[p];
             t = a.seq + a.t_off[p] + s0;
         }
+        // Diagonals (row - column) an optimal path can touch: it starts on diagonal 0, ends on delta = m - L and
+        // pays one edit per diagonal change, so |d| + |delta - d| <= ed, i.e. d in [min(0, delta) - h, max(0, delta) + h]
+        // with h = (ed - |delta|) / 2: ed + 1 diagonals, not 2 ed + 1.  The window (bit b <-> diagonal b - TOP + off)
+        // is shifted per lane so that its lowest diagonal sits just above that range; off is kept a multiple of 8
+        // so that the 8-byte query window refills together with the target's.
+        const int delta = m - L;
+        const int hh = (ed - (delta < 0 ? -delta : delta)) >> 1;
+        const int off = ((delta < 0 ? delta : 0) - hh - 1 + TOP) & ~7;
         uint64_t PL[NP][WB], VP[WB], VN[WB];
         uint64_t qw = 0, tw = 0;
         int ri = 0; // next query row to enter the window
         auto insert_row = [&]() {
-            if ((ri & 7) == 0) qw = ri < m ? load8(q + ri) : 0;
-            const uint32_t code1 = ri < m ? (uint32_t)(qw & 0xff) + 1u : 0u; // 0 = outside the query: matches nothing
+            const bool inq = ri >= 0 && ri < m;
+            if ((ri & 7) == 0) qw = inq ? load8(q + ri) : 0;
+            const uint32_t code1 = inq ? (uint32_t)(qw & 0xff) + 1u : 0u; // 0 = outside the query: matches nothing
             qw >>= 8;
             ri++;
 #pragma unroll
@@ -589,12 +600,18 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
         for (int k = 0; k < NP; k++)
 #pragma unroll
             for (int w = 0; w < WB; w++) PL[k][w] = 0;
-        for (int i = 0; i <= TOP; i++) insert_row(); // rows 0 .. TOP: the window of column -1
+        // the window of column -1 holds rows off - TOP - 1 .. off + TOP; those above row 0 are virtual (planes 0)
+        {
+            const int r_end = TOP + 1 + off, r0 = off - TOP - 1;
+            ri = r0 < 0 ? (r_end < 0 ? r_end : 0) : r0;
+            while (ri < r_end) insert_row();
+        }
         // column -1: D[r][-1] = r + 1 for query rows, 0 for the virtual rows above row 0
 #pragma unroll
         for (int w = 0; w < WB; w++) {
-            // bit b <-> row -1 - TOP + b >= 0  <=>  b >= TOP + 1 = 32*WB
-            VP[w] = (64 * w >= TOP + 1) ? ~(uint64_t)0 : (64 * (w + 1) <= TOP + 1 ? 0 : (~(uint64_t)0) << ((TOP + 1) & 63));
+            // bit b <-> row -1 - TOP + off + b >= 0  <=>  b >= TOP + 1 - off
+            const int z = TOP + 1 - off - 64 * w;
+            VP[w] = z <= 0 ? ~(uint64_t)0 : z >= 64 ? 0 : (~(uint64_t)0) << z;
             VN[w] = 0;
         }
         const int Lmax = wave_max_i32(L);
@@ -629,11 +646,11 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
 #pragma unroll
                     for (int w = 0; w < WB; w++) PL[k][w] = cp[((2 + k) * WB + w) * 64];
             }
-            ri = TOP + 1 + c0; // rows entered so far (a multiple of 8, like c0: both byte windows refill at once)
+            ri = TOP + 1 + off + c0; // rows entered so far (a multiple of 8, like c0: both byte windows refill at once)
             for (int k = 0; k < K; k++) column(c0 + k, k, true);
             if (act) {
                 while (r >= 0 && c >= c0) {
-                    const int b = r - c + TOP;
+                    const int b = r - c + TOP - off;
                     const ulonglong2 e = col[((c - c0) * WB + (b >> 6)) * 64];
                     const uint64_t bit = ((uint64_t)1) << (b & 63);
                     if (e.x & bit) { ins++; r--; }
@@ -670,7 +687,8 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
     const int ed = a.ed[p];
     const int64_t lo = a.loc_off[p];
     const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
-    const uint32_t c = ed <= 30 ? 0 : ed <= 62 ? 1 : ed <= 126 ? 2 : ed <= 254 ? 3 : kBandFallback;
+    // ed + 1 diagonals, one spare on either side, up to 7 lost to the window's 8-row alignment: ed <= 64 WB - 10
+    const uint32_t c = ed <= 54 ? 0 : ed <= 118 ? 1 : ed <= 246 ? 2 : ed <= 502 ? 3 : kBandFallback;
     if (c < kBandFallback) keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
     else keys[i] = (c << kBandLBits) | (size_class_of(a.q_len[p]) << kFullLBits) | (((1u << kFullLBits) - 1u) - (L < (1u << kFullLBits) ? L : (1u << kFullLBits) - 1u));
 }
