@@ -108,6 +108,16 @@ template <int TT> __device__ __forceinline__ uint32_t bop3(uint32_t a, uint32_t 
     return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
 }
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+template <int TT> __device__ __forceinline__ uint64_t bop3_64(uint64_t a, uint64_t b, uint64_t c)
+{
+    return pack64(bop3<TT>((uint32_t)a, (uint32_t)b, (uint32_t)c), bop3<TT>((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)));
+}
+// (x >> 1) | (next << 63): two v_alignbit_b32
+__device__ __forceinline__ uint64_t shr1_in(uint64_t x, uint32_t next_lo)
+{
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    return pack64(__builtin_amdgcn_alignbit(xh, xl, 1), __builtin_amdgcn_alignbit(next_lo, xh, 1));
+}
 __device__ __forceinline__ void word_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t &hp, uint32_t &hm, uint64_t &Ph0)
 {
     const uint32_t pvl = (uint32_t)Pv, pvh = (uint32_t)(Pv >> 32), mvl = (uint32_t)Mv, mvh = (uint32_t)(Mv >> 32);
@@ -556,8 +566,8 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
 #pragma unroll
             for (int k = 0; k < NP; k++) {
 #pragma unroll
-                for (int w = 0; w < WB - 1; w++) PL[k][w] = (PL[k][w] >> 1) | (PL[k][w + 1] << 63);
-                PL[k][WB - 1] = (PL[k][WB - 1] >> 1) | ((uint64_t)((code1 >> k) & 1u) << 63);
+                for (int w = 0; w < WB - 1; w++) PL[k][w] = shr1_in(PL[k][w], (uint32_t)PL[k][w + 1]);
+                PL[k][WB - 1] = shr1_in(PL[k][WB - 1], code1 >> k);
             }
         };
         // one column of the banded recurrence; STORE: leave {Pv, Ph} of the column in LDS slot k
@@ -565,14 +575,23 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
             if ((c & 7) == 0) tw = c < L ? load8(t + c) : 0;
             const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
             tw >>= 8;
+            // match vector: bit set where every plane of the query code equals the target's bit (XNOR per plane,
+            // the target's bits as per-lane all-0 / all-1 masks); three-input ops on 32-bit halves throughout
             uint64_t Eq[WB];
+            {
+                uint32_t mk[NP];
 #pragma unroll
-            for (int w = 0; w < WB; w++) Eq[w] = ~(uint64_t)0;
+                for (int kk = 0; kk < NP; kk++) mk[kk] = ((tc1 >> kk) & 1u) - 1u; // bit set -> 0, clear -> ~0
 #pragma unroll
-            for (int kk = 0; kk < NP; kk++) {
-                const uint64_t mk = ((tc1 >> kk) & 1u) ? 0 : ~(uint64_t)0;
+                for (int w = 0; w < WB; w++) {
+                    uint32_t el = (uint32_t)PL[0][w] ^ mk[0], eh = (uint32_t)(PL[0][w] >> 32) ^ mk[0];
 #pragma unroll
-                for (int w = 0; w < WB; w++) Eq[w] &= PL[kk][w] ^ mk;
+                    for (int kk = 1; kk < NP; kk++) {
+                        el = bop3<0x60>(el, (uint32_t)PL[kk][w], mk[kk]);         // a & (b ^ c)
+                        eh = bop3<0x60>(eh, (uint32_t)(PL[kk][w] >> 32), mk[kk]);
+                    }
+                    Eq[w] = pack64(el, eh);
+                }
             }
             uint64_t D0[WB], HP[WB], HN[WB];
             uint64_t carry = 0;
@@ -582,17 +601,20 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
                 const uint64_t s1 = x + VP[w];
                 const uint64_t s2 = s1 + carry;
                 carry = (uint64_t)((s1 < x) | (s2 < s1));
-                D0[w] = (s2 ^ VP[w]) | Eq[w] | VN[w];
-                HP[w] = VN[w] | ~(D0[w] | VP[w]);
+                D0[w] = bop3_64<0xBE>(s2, VP[w], Eq[w]) | VN[w]; // (s2 ^ VP) | Eq | VN
+                HP[w] = bop3_64<0xF1>(VN[w], D0[w], VP[w]);      // VN | ~(D0 | VP)
                 HN[w] = D0[w] & VP[w];
             }
 #pragma unroll
             for (int w = 0; w < WB; w++) {
-                const uint64_t X = (D0[w] >> 1) | (w + 1 < WB ? (D0[w + 1] << 63) : 0);
-                const uint64_t hps = (HP[w] >> 1) | (w + 1 < WB ? (HP[w + 1] << 63) : 0); // Ph in this column's alignment
+                const uint64_t X = shr1_in(D0[w], w + 1 < WB ? (uint32_t)D0[w + 1] : 0u);
                 VN[w] = X & HP[w];
-                VP[w] = HN[w] | ~(X | HP[w]);
-                if (store) { ulonglong2 e; e.x = VP[w]; e.y = hps; col[(k * WB + w) * 64] = e; }
+                VP[w] = bop3_64<0xF1>(HN[w], X, HP[w]);          // HN | ~(X | HP)
+                if (store) {
+                    ulonglong2 e; e.x = VP[w];
+                    e.y = shr1_in(HP[w], w + 1 < WB ? (uint32_t)HP[w + 1] : 0u); // Ph in this column's alignment
+                    col[(k * WB + w) * 64] = e;
+                }
             }
             insert_row();
         };
