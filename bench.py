@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = min(16, available cores)")
     ap.add_argument("--contexts", type=int, default=1, help="independent library contexts (host threads) per GPU; "
                     "each runs 1/N of the step's reads so that the passes of different sub-batches overlap")
+    ap.add_argument("--stagger-ms", type=float, default=4.0, help="start offset between the contexts' loops (--contexts > 1)")
+    ap.add_argument("--lanes", type=int, default=0, help="launch lanes (HIP streams) per context, 0 = library default (4)")
     ap.add_argument("--check", type=int, default=64, help="instances of the last step verified against the oracle")
     return ap.parse_args()
 
@@ -117,7 +119,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import threading
     NC = max(1, args.contexts)
-    ctxs = [lib.Context(local) for _ in range(NC)]
+    ctxs = [lib.Context(local, cfg={"launch_lanes": args.lanes} if args.lanes else None) for _ in range(NC)]
     ctx = ctxs[0]
     info = ctx.device_info()
     if NC == 1:
@@ -158,16 +160,43 @@ def main():
     build_ms = chain_ms = gather_ms = 0.0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_all()
-        for c in ctxs:
-            _, ms = c.myers_timing()
-            fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]; fwdk_ms += ms[4]
-            mm = c.mam_timing()
-            build_ms += mm[0]; chain_ms += mm[1]; gather_ms += mm[2]
-            for key, (cc, t) in c.myers_class_timing().items():
-                a = class_ms.setdefault(key, [0.0, 0.0, 0])
-                a[0] += cc; a[1] += t; a[2] += 1
+
+    def collect(c):
+        nonlocal fwd_ms, rev_ms, tb_ms, all_ms, fwdk_ms, build_ms, chain_ms, gather_ms
+        _, ms = c.myers_timing()
+        fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]; fwdk_ms += ms[4]
+        mm = c.mam_timing()
+        build_ms += mm[0]; chain_ms += mm[1]; gather_ms += mm[2]
+        for key, (cc, t) in c.myers_class_timing().items():
+            a = class_ms.setdefault(key, [0.0, 0.0, 0])
+            a[0] += cc; a[1] += t; a[2] += 1
+
+    if NC == 1:
+        for _ in range(args.steps):
+            run_all()
+            collect(ctx)
+    else:
+        # Sub-batches in flight on one GPU: every context runs its K steps back to back from its own host thread,
+        # started half a pass apart, so that the latency-bound passes of one (traceback, MAM build, chaining)
+        # overlap with the throughput-bound ones (forward, starts) of the other.
+        errs, lock = [], threading.Lock()
+
+        def loop(i, c):
+            try:
+                time.sleep(i * args.stagger_ms * 1e-3)
+                for _ in range(args.steps):
+                    stage.run_staged(c, P["min_acc"])
+                    with lock:
+                        collect(c)
+            except Exception as e:   # surfaced below
+                errs.append(e)
+        th = [threading.Thread(target=loop, args=(i, c)) for i, c in enumerate(ctxs)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
     barrier()
     elapsed = time.perf_counter() - t0
     # results back to the host (PCIe; outside the timed region, reported separately)

@@ -104,7 +104,7 @@ struct ultra_ctx {
     hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {nullptr, nullptr, nullptr};
     // lane i of a forked section: the three auxiliary streams, then the main stream itself
-    hipStream_t lane(int i) const { i %= kLanes; return i < kAuxStreams ? aux[i] : stream; }
+    hipStream_t lane(int i) const { i %= cfg.launch_lanes; return i < cfg.launch_lanes - 1 ? aux[i] : stream; }
     ultra_cfg cfg;
     std::string err;
     hipDeviceProp_t prop;
@@ -128,13 +128,13 @@ struct ultra_ctx {
 static inline hipError_t ultra_fork(ultra_ctx *ctx)
 {
     hipError_t e = hipEventRecord(ctx->fork_ev, ctx->stream);
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; i++) e = hipStreamWaitEvent(ctx->aux[i], ctx->fork_ev, 0);
+    for (int i = 0; i < ctx->cfg.launch_lanes - 1 && e == hipSuccess; i++) e = hipStreamWaitEvent(ctx->aux[i], ctx->fork_ev, 0);
     return e;
 }
 static inline hipError_t ultra_join(ultra_ctx *ctx)
 {
     hipError_t e = hipSuccess;
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; i++) {
+    for (int i = 0; i < ctx->cfg.launch_lanes - 1 && e == hipSuccess; i++) {
         e = hipEventRecord(ctx->join_ev[i], ctx->aux[i]);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->join_ev[i], 0);
     }

@@ -405,15 +405,16 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         const int steps = nmax + G - 1;
         uint32_t h_out = 0; // bit 0: +1 carry out of this lane's last word, bit 1: -1 carry
         uint64_t tw = 0;    // this lane's next target bytes (its column lags g steps behind lane 0)
+        uint64_t twn = n > 0 ? load8(it.t) : 0; // the chunk after it, loaded eight columns ahead of its use
         for (int t = 0; t < steps; t++) {
-            // the carry moves one lane down per step: a DPP row shift inside a 16-lane group, a shuffle otherwise
+            // the carry moves one lane down per step: a DPP shift (inside a 16-lane row, or across the whole wavefront)
             uint32_t h_in = G <= 16 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x111 /* row_shr:1 */, 0xf, 0xf, false)
-                                    : (uint32_t)__shfl_up((int)h_out, 1, 64);
+                                    : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             if (g == 0) h_in = top_hp;
             uint32_t hp = h_in & 1u, hm = h_in >> 1;
             const int col = t - g;
             if (col >= 0 && col < n) {
-                if ((col & 7) == 0) tw = load8(it.t + col);
+                if ((col & 7) == 0) { tw = twn; if (col + 8 < n) twn = load8(it.t + col + 8); }
                 const int code = (int)(tw & 0xff);
                 tw >>= 8;
                 const uint64_t *pe = peq + (size_t)code * NB + g * W;
@@ -491,12 +492,17 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
     } else if (BUCKET == 2) {
         if (wi.cls == 4) group_item<2, 3, MODE>(a, wi.base, lds, 0); else group_item<2, 4, MODE>(a, wi.base, lds, 0);
     } else if (BUCKET == 3) {
-        if (wi.cls == 6) group_item<4, 4, MODE>(a, wi.base, lds, 0); else group_item<8, 4, MODE>(a, wi.base, lds, 0);
+        switch (wi.cls) {
+        case 6: group_item<4, 3, MODE>(a, wi.base, lds, 0); break;
+        case 7: group_item<4, 4, MODE>(a, wi.base, lds, 0); break;
+        case 8: group_item<8, 3, MODE>(a, wi.base, lds, 0); break;
+        default: group_item<8, 4, MODE>(a, wi.base, lds, 0); break;
+        }
     } else {
         switch (wi.cls) {
-        case 8: group_item<64, 1, MODE>(a, wi.base, lds, 0); break;
-        case 9: group_item<64, 2, MODE>(a, wi.base, lds, 0); break;
-        case 10: group_item<64, 4, MODE>(a, wi.base, lds, 0); break;
+        case 10: group_item<64, 1, MODE>(a, wi.base, lds, 0); break;
+        case 11: group_item<64, 2, MODE>(a, wi.base, lds, 0); break;
+        case 12: group_item<64, 4, MODE>(a, wi.base, lds, 0); break;
         default: group_item<64, 8, MODE>(a, wi.base, lds, 0); break;
         }
     }
@@ -694,12 +700,12 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
 // every band class are keyed by the size class of their query instead: each full-height kernel then
 // gets a dense list of exactly its hits.
 constexpr uint32_t kBandLBits = 24, kFullLBits = 20;
-constexpr int kNumSizeClasses = 12;
+constexpr int kNumSizeClasses = 14;
 constexpr int kBandBounds = kBandClasses + kNumSizeClasses + 1; // first sorted position of each group, then the end
 __device__ __forceinline__ uint32_t size_class_of(int m)
 {
-    return m <= 256 ? (uint32_t)((m - 1) >> 6) : m <= 384 ? 4u : m <= 512 ? 5u : m <= 1024 ? 6u : m <= 2048 ? 7u
-         : m <= 4096 ? 8u : m <= 8192 ? 9u : m <= 16384 ? 10u : 11u;
+    return m <= 256 ? (uint32_t)((m - 1) >> 6) : m <= 384 ? 4u : m <= 512 ? 5u : m <= 768 ? 6u : m <= 1024 ? 7u : m <= 1536 ? 8u
+         : m <= 2048 ? 9u : m <= 4096 ? 10u : m <= 8192 ? 11u : m <= 16384 ? 12u : 13u;
 }
 __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys)
 {
@@ -820,10 +826,11 @@ __global__ void k_fill(const int32_t *ed, const int32_t *nloc, const int32_t *sl
 struct ClassDef { int G, W; };
 // rows = 64*G*W ascending
 const ClassDef kClasses[] = {
-    {1, 1}, {1, 2}, {1, 3}, {1, 4},       // <= 256 rows: lane per pair
-    {2, 3}, {2, 4}, {4, 4}, {8, 4},       // 384, 512, 1024, 2048 rows: 2..8 lanes per pair
-    {64, 1}, {64, 2}, {64, 4}, {64, 8},   // 4096 .. 32768 rows: wavefront per pair
+    {1, 1}, {1, 2}, {1, 3}, {1, 4},                   // <= 256 rows: lane per pair
+    {2, 3}, {2, 4}, {4, 3}, {4, 4}, {8, 3}, {8, 4},   // 384, 512, 768, 1024, 1536, 2048 rows: 2..8 lanes per pair
+    {64, 1}, {64, 2}, {64, 4}, {64, 8},               // 4096 .. 32768 rows: wavefront per pair
 };
+static_assert(sizeof(kClasses) / sizeof(kClasses[0]) == kNumSizeClasses, "size_class_of() and kClasses must agree");
 constexpr int kNumClasses = sizeof(kClasses) / sizeof(kClasses[0]);
 constexpr int kMaxQuery = 64 * 64 * 8;
 constexpr int kMaxSymbols = 16;
@@ -871,18 +878,20 @@ template <int MODE> hipError_t launch_class(hipStream_t ctx, int cls, const MyAr
     case 3: return launch_lane<4, MODE>(ctx, a, items, max_par);
     case 4: return launch_group<2, 3, MODE>(ctx, a, items, max_par);
     case 5: return launch_group<2, 4, MODE>(ctx, a, items, max_par);
-    case 6: return launch_group<4, 4, MODE>(ctx, a, items, max_par);
-    case 7: return launch_group<8, 4, MODE>(ctx, a, items, max_par);
-    case 8: return launch_group<64, 1, MODE>(ctx, a, items, max_par);
-    case 9: return launch_group<64, 2, MODE>(ctx, a, items, max_par);
-    case 10: return launch_group<64, 4, MODE>(ctx, a, items, max_par);
-    case 11: return launch_group<64, 8, MODE>(ctx, a, items, max_par);
+    case 6: return launch_group<4, 3, MODE>(ctx, a, items, max_par);
+    case 7: return launch_group<4, 4, MODE>(ctx, a, items, max_par);
+    case 8: return launch_group<8, 3, MODE>(ctx, a, items, max_par);
+    case 9: return launch_group<8, 4, MODE>(ctx, a, items, max_par);
+    case 10: return launch_group<64, 1, MODE>(ctx, a, items, max_par);
+    case 11: return launch_group<64, 2, MODE>(ctx, a, items, max_par);
+    case 12: return launch_group<64, 4, MODE>(ctx, a, items, max_par);
+    case 13: return launch_group<64, 8, MODE>(ctx, a, items, max_par);
     }
     return hipErrorInvalidValue;
 }
 
 constexpr int kBuckets = 5;
-inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 8 ? 3 : 4; }
+inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 10 ? 3 : 4; }
 inline int bucket_wmax(int b) { return b == 0 ? 2 : b < 4 ? 4 : 8; } // words per lane: LDS per wavefront = S * wmax * 512 B
 
 // work items of one pass: for every class the item range [b, e) cut into wavefront-sized pieces
