@@ -50,6 +50,7 @@ def parse_args():
                     "each runs 1/N of the step's reads so that the passes of different sub-batches overlap")
     ap.add_argument("--stagger-ms", type=float, default=4.0, help="start offset between the contexts' loops (--contexts > 1)")
     ap.add_argument("--lanes", type=int, default=0, help="launch lanes (HIP streams) per context, 0 = library default (4)")
+    ap.add_argument("--slots", type=int, default=0, help="end positions kept per pair in the first pass, 0 = library default")
     ap.add_argument("--check", type=int, default=64, help="instances of the last step verified against the oracle")
     return ap.parse_args()
 
@@ -119,7 +120,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import threading
     NC = max(1, args.contexts)
-    ctxs = [lib.Context(local, cfg={"launch_lanes": args.lanes} if args.lanes else None) for _ in range(NC)]
+    cfg = {}
+    if args.lanes:
+        cfg["launch_lanes"] = args.lanes
+    if args.slots:
+        cfg["loc_slots"] = args.slots
+    ctxs = [lib.Context(local, cfg=cfg or None) for _ in range(NC)]
     ctx = ctxs[0]
     info = ctx.device_info()
     if NC == 1:

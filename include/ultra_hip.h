@@ -40,7 +40,7 @@ typedef struct ultra_cfg {
     int32_t chain_switch_n;   /* > this many MAMs -> n log n solver   (classify_read_with_mams.py:561)  = 200 */
     int32_t overlap_small;    /* overlap threshold of the quadratic solver (classify_read_with_mams.py:575) = 20 */
     int32_t overlap_large;    /* overlap threshold of the n log n solver   (classify_read_with_mams.py:563) = 5 */
-    int32_t loc_slots;        /* end positions kept per pair in the first pass before the exact re-run = 8 */
+    int32_t loc_slots;        /* end positions kept per pair in the first pass before the exact re-run = 32 */
     int32_t banded_traceback; /* 1 = first-location traceback in a diagonal band sized by the known distance
                                  (same results, far less work); 0 = full-height columns everywhere        = 1 */
     int32_t nam_switch_n;     /* >= this many NAMs -> n log n NAM solver (align.py:448)                      = 90 */

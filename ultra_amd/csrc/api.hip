@@ -12,7 +12,7 @@ void ultra_cfg_default(ultra_cfg *cfg)
     cfg->chain_switch_n = 200; // classify_read_with_mams.py:561
     cfg->overlap_small = 20;   // classify_read_with_mams.py:575
     cfg->overlap_large = 5;    // classify_read_with_mams.py:563
-    cfg->loc_slots = 8;
+    cfg->loc_slots = 32;
     cfg->banded_traceback = 1;
     cfg->nam_switch_n = 90;    // align.py:448
     cfg->launch_lanes = 4;

@@ -48,7 +48,7 @@ struct WorkItem {
 
 // Register bucket of size classes: one launch per pass and bucket (myers_mega<MODE, BUCKET>).
 struct MyersBucket {
-    DevBuf fwd_list, rev_list;
+    DevBuf fwd_list, rev_list, fwd_flag;
     int32_t n_fwd = 0, n_rev = 0;
     int wmax = 0;
     double cells = 0;   // forward-pass cells (sum of q_len * t_len) of the bucket's pairs

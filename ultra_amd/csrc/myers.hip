@@ -42,6 +42,7 @@ struct MyArgs {
     int32_t Lmax;
     uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
     int64_t begin, end;
+    int32_t *wflag; // per work item of a forward launch: some pair has more end columns than first-pass slots
 };
 
 struct Item {
@@ -328,6 +329,8 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
         }
         if (MODE == MODE_FWD) {
             if (it.valid) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
+            const bool over = __any(it.valid && cnt > out_cap);
+            if (a.wflag && lane == 0) a.wflag[blockIdx.x] = over;
         } else if (MODE == MODE_REV) {
             if (it.valid) a.loc_start[base + lane] = a.loc_end[base + lane] - last;
         } else if (MODE == MODE_NW) {
@@ -444,6 +447,8 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         }
         if (MODE == MODE_FWD) {
             if (it.valid && g == G - 1) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
+            const bool over = __any(it.valid && g == G - 1 && cnt > out_cap);
+            if (a.wflag && lane == 0) a.wflag[blockIdx.x] = over;
         } else if (MODE == MODE_REV) {
             if (it.valid && g == G - 1) a.loc_start[base + p] = a.loc_end[base + p] - last;
         } else if (MODE == MODE_NW) {
@@ -483,6 +488,7 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
 {
     extern __shared__ uint64_t lds[];
     if ((int32_t)blockIdx.x >= n) return;
+    if (MODE == MODE_FWD_EXACT && !a.wflag[blockIdx.x]) return; // the forward launch over the same list left the flag
     const WorkItem wi = list[blockIdx.x];
     a.end = wi.end;
     if (BUCKET == 0) {
@@ -918,9 +924,10 @@ void build_work(const std::vector<PassRange> &ranges, std::vector<WorkItem> out[
         std::stable_sort(out[b].begin(), out[b].end(), [](const WorkItem &x, const WorkItem &y) { return x.cost > y.cost; });
 }
 
-template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, const MyArgs &a, int bucket, const WorkItem *d_list, int32_t n)
+template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket, const WorkItem *d_list, int32_t n)
 {
     if (n <= 0) return hipSuccess;
+    a.wflag = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ctx->my.buckets[bucket].fwd_flag.as<int32_t>() : nullptr;
     const size_t shmem = (size_t)a.S * bucket_wmax(bucket) * 64 * sizeof(uint64_t);
     hipStream_t cs = ctx->lane(bucket);
     const void *fn = bucket == 0 ? (const void *)myers_mega<MODE, 0> : bucket == 1 ? (const void *)myers_mega<MODE, 1>
@@ -983,7 +990,7 @@ void ultra_myers_free(ultra_ctx *ctx)
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto &bk : st.buckets) {
-        bk.fwd_list.release(); bk.rev_list.release();
+        bk.fwd_list.release(); bk.rev_list.release(); bk.fwd_flag.release();
         if (bk.ev0) { (void)hipEventDestroy(bk.ev0); bk.ev0 = nullptr; }
         if (bk.ev1) { (void)hipEventDestroy(bk.ev1); bk.ev1 = nullptr; }
     }
@@ -1095,6 +1102,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
             if (!bk.ev0) { ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev0)); ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev1)); }
             if (bk.n_fwd <= 0) continue;
             ULTRA_HIP_CHECK(ctx, bk.fwd_list.ensure(st.h_work[b].size() * sizeof(WorkItem)));
+            ULTRA_HIP_CHECK(ctx, bk.fwd_flag.ensure(st.h_work[b].size() * sizeof(int32_t)));
             ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(bk.fwd_list.p, st.h_work[b].data(), st.h_work[b].size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
         }
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
