@@ -24,6 +24,10 @@ import os
 import sys
 import time
 
+# Eight hardware queues instead of HIP's default four: the launches of one pass (five forward buckets, seven
+# traceback kernels) then all run side by side.  Must be in the environment before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

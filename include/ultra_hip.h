@@ -44,8 +44,8 @@ typedef struct ultra_cfg {
     int32_t banded_traceback; /* 1 = first-location traceback in a diagonal band sized by the known distance
                                  (same results, far less work); 0 = full-height columns everywhere        = 1 */
     int32_t nam_switch_n;     /* >= this many NAMs -> n log n NAM solver (align.py:448)                      = 90 */
-    int32_t launch_lanes;     /* HIP streams the independent launches of one pass are dealt over, 1..4 (a process
-                                 has 4 hardware queues: use 2 when two contexts share a GPU)                  = 4 */
+    int32_t launch_lanes;     /* HIP streams the independent launches of one pass are dealt over, 1..8; 0 = one per
+                                 hardware queue of the process (GPU_MAX_HW_QUEUES in the environment, else 4) = 0 */
 } ultra_cfg;
 
 void ultra_cfg_default(ultra_cfg *cfg);

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: one hardware queue per launch lane
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

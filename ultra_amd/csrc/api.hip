@@ -15,7 +15,7 @@ void ultra_cfg_default(ultra_cfg *cfg)
     cfg->loc_slots = 32;
     cfg->banded_traceback = 1;
     cfg->nam_switch_n = 90;    // align.py:448
-    cfg->launch_lanes = 4;
+    cfg->launch_lanes = 0;
 }
 
 int ultra_device_count(void)
@@ -35,7 +35,13 @@ int ultra_ctx_create(int device, const ultra_cfg *cfg, ultra_ctx **out)
     ultra_ctx *ctx = new ultra_ctx();
     ctx->device = device;
     if (cfg) ctx->cfg = *cfg; else ultra_cfg_default(&ctx->cfg);
-    if (ctx->cfg.loc_slots < 1 || ctx->cfg.loc_slots > 1024 || ctx->cfg.launch_lanes < 1 || ctx->cfg.launch_lanes > kLanes) { delete ctx; return ULTRA_E_ARG; }
+    if (ctx->cfg.loc_slots < 1 || ctx->cfg.loc_slots > 1024 || ctx->cfg.launch_lanes < 0 || ctx->cfg.launch_lanes > kLanes) { delete ctx; return ULTRA_E_ARG; }
+    if (ctx->cfg.launch_lanes == 0) {
+        // one lane per hardware queue of the process: HIP's default is 4, GPU_MAX_HW_QUEUES raises it
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        const int nq = q ? atoi(q) : 4;
+        ctx->cfg.launch_lanes = nq < 1 ? 1 : nq > kLanes ? kLanes : nq;
+    }
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) { delete ctx; return ULTRA_E_HIP; }
     // the code object is built for gfx950 only; refuse anything else loudly
     if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return ULTRA_E_NODEVICE; }

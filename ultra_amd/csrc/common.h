@@ -93,16 +93,19 @@ struct MamState {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
-constexpr int kAuxStreams = 3;  // + the main stream = 4 lanes; a fifth stream would share a hardware queue (4 per process)
-constexpr int kLanes = 4;
+// Launch lanes = HIP streams the independent launches of a pass are dealt over.  Streams beyond the process's
+// hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise before the first HIP call) share a
+// queue and serialise, so the default lane count follows that variable (ultra_ctx_create).
+constexpr int kAuxStreams = 7;
+constexpr int kLanes = kAuxStreams + 1;
 
 struct ultra_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // size classes of one pass are independent: they are launched round-robin on these streams so
     // that short launches overlap (fork = aux streams wait for `stream`, join = `stream` waits for them)
-    hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {nullptr, nullptr, nullptr};
+    hipStream_t aux[kAuxStreams] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {};
     // lane i of a forked section: the three auxiliary streams, then the main stream itself
     hipStream_t lane(int i) const { i %= cfg.launch_lanes; return i < cfg.launch_lanes - 1 ? aux[i] : stream; }
     ultra_cfg cfg;

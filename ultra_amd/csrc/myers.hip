@@ -567,14 +567,19 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
         const int hh = (ed - (delta < 0 ? -delta : delta)) >> 1;
         const int off = ((delta < 0 ? delta : 0) - hh - 1 + TOP) & ~7;
         uint64_t PL[NP][WB], VP[WB], VN[WB];
-        uint64_t qw = 0, tw = 0;
-        int ri = 0; // next query row to enter the window
-        auto insert_row = [&]() {
-            const bool inq = ri >= 0 && ri < m;
-            if ((ri & 7) == 0) qw = inq ? load8(q + ri) : 0;
-            const uint32_t code1 = inq ? (uint32_t)(qw & 0xff) + 1u : 0u; // 0 = outside the query: matches nothing
-            qw >>= 8;
-            ri++;
+        // Target and query bytes, eight at a time.  Column c consumes target byte c and query row TOP + 1 + off + c
+        // (both multiples of 8 together), so one prefetch fetches the two 8-byte blocks a group of eight columns
+        // starts with; it is issued a whole group ahead (these kernels run at one or two wavefronts per SIMD:
+        // nothing else hides a load).
+        uint64_t qw = 0, tw = 0, qwn = 0, twn = 0;
+        int pref_c = -0x40000000; // column group the blocks in twn / qwn belong to
+        auto qblock = [&](int r) { return (r >= 0 && r < m) ? load8(q + r) : (uint64_t)0; };
+        auto prefetch = [&](int cn) {
+            pref_c = cn;
+            twn = (cn >= 0 && cn < L) ? load8(t + cn) : 0;
+            qwn = qblock(TOP + 1 + off + cn);
+        };
+        auto push_row = [&](uint32_t code1) { // code + 1 of the row entering at the bottom; 0 = outside the query: matches nothing
 #pragma unroll
             for (int k = 0; k < NP; k++) {
 #pragma unroll
@@ -582,9 +587,14 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
                 PL[k][WB - 1] = shr1_in(PL[k][WB - 1], code1 >> k);
             }
         };
-        // one column of the banded recurrence; STORE: leave {Pv, Ph} of the column in LDS slot k
-        auto column = [&](int c, int k, bool store) {
-            if ((c & 7) == 0) tw = c < L ? load8(t + c) : 0;
+        // one column of the banded recurrence; STORE: leave {Pv, Ph} of the column in LDS slot k.
+        // next_c: the column group to prefetch when this column opens a group
+        auto column = [&](int c, int k, bool store, int next_c) {
+            if ((c & 7) == 0) {
+                if (pref_c != c) prefetch(c); // not staged ahead: first group of a sweep, or chunks were skipped
+                tw = twn; qw = qwn;
+                prefetch(next_c);
+            }
             const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
             tw >>= 8;
             // match vector: bit set where every plane of the query code equals the target's bit (XNOR per plane,
@@ -628,7 +638,11 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
                     col[(k * WB + w) * 64] = e;
                 }
             }
-            insert_row();
+            {
+                const int r = TOP + 1 + off + c; // the row that enters the window for column c + 1
+                push_row((r >= 0 && r < m) ? (uint32_t)(qw & 0xff) + 1u : 0u);
+                qw >>= 8;
+            }
         };
 #pragma unroll
         for (int k = 0; k < NP; k++)
@@ -637,8 +651,14 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
         // the window of column -1 holds rows off - TOP - 1 .. off + TOP; those above row 0 are virtual (planes 0)
         {
             const int r_end = TOP + 1 + off, r0 = off - TOP - 1;
-            ri = r0 < 0 ? (r_end < 0 ? r_end : 0) : r0;
-            while (ri < r_end) insert_row();
+            int ri = r0 < 0 ? (r_end < 0 ? r_end : 0) : r0; // multiples of 8
+            uint64_t cur = 0, nxt = qblock(ri);
+            while (ri < r_end) {
+                if ((ri & 7) == 0) { cur = nxt; nxt = qblock(ri + 8); }
+                push_row((ri >= 0 && ri < m) ? (uint32_t)(cur & 0xff) + 1u : 0u);
+                cur >>= 8;
+                ri++;
+            }
         }
         // column -1: D[r][-1] = r + 1 for query rows, 0 for the virtual rows above row 0
 #pragma unroll
@@ -662,7 +682,7 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
                     for (int w = 0; w < WB; w++) cp[((2 + k) * WB + w) * 64] = PL[k][w];
             }
             if (h + 1 < nchunk) // the last chunk is recomputed first anyway
-                for (int k = 0; k < K; k++) column(h * K + k, k, false);
+                for (int k = 0; k < K; k++) column(h * K + k, k, false, h * K + k + 8);
         }
         // ---- backwards through the chunks: recompute into LDS, walk inside LDS ----
         int r = m - 1, c = L - 1, ins = 0;
@@ -680,8 +700,8 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
 #pragma unroll
                     for (int w = 0; w < WB; w++) PL[k][w] = cp[((2 + k) * WB + w) * 64];
             }
-            ri = TOP + 1 + off + c0; // rows entered so far (a multiple of 8, like c0: both byte windows refill at once)
-            for (int k = 0; k < K; k++) column(c0 + k, k, true);
+            // next group in processing order: the rest of this chunk, then the chunk before it
+            for (int k = 0; k < K; k++) column(c0 + k, k, true, k + 8 < K ? c0 + k + 8 : c0 - K);
             if (act) {
                 while (r >= 0 && c >= c0) {
                     const int b = r - c + TOP - off;
@@ -1357,7 +1377,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             b.region = it->region; b.Lmax = (int32_t)it->Lmax;
             b.begin = it->begin; b.end = it->end;
             b.nw_items = use_band ? d_items_sorted : nullptr;
-            ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->aux[(q + 1) % kAuxStreams], it->cls, b, it->items, it->max_par));
+            ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->lane(kBandClasses + q), it->cls, b, it->items, it->max_par));
         }
     }
     if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
