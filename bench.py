@@ -26,7 +26,7 @@ import time
 
 # Eight hardware queues instead of HIP's default four: the launches of one pass (five forward buckets, seven
 # traceback kernels) then all run side by side.  Must be in the environment before the first HIP call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("ULTRA_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

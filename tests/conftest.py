@@ -1,7 +1,7 @@
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: one hardware queue per launch lane
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("ULTRA_HW_QUEUES", "8")  # before the first HIP call: one hardware queue per launch lane
 
 import pytest
 

@@ -109,7 +109,7 @@ def test_round_trip_property_at_scale(ctx):
 
 def test_banded_and_full_height_traceback_agree(ctx):
     """The banded traceback (default) and the full-height one (cfg banded_traceback=0, also the
-    fallback for distances > 502) give the same insertion counts; both equal the oracle."""
+    fallback for distances > 374) give the same insertion counts; both equal the oracle."""
     from ultra_amd import lib
     rng = np.random.RandomState(11)
     full = lib.Context(0, cfg={"banded_traceback": 0})
@@ -121,7 +121,7 @@ def test_banded_and_full_height_traceback_agree(ctx):
             a = _check(ctx, pairs)
             b = _check(full, pairs)
             assert np.array_equal(a["first_ins"], b["first_ins"])
-            assert (a["ed"] > 502).any() or qr[0] < 1300
+            assert (a["ed"] > 374).any() or qr[0] < 1300
     finally:
         full.close()
 
@@ -135,7 +135,7 @@ def test_banded_traceback_wide_alphabet(ctx):
 def test_banded_traceback_skewed_paths(ctx, mix):
     """The band is shifted per pair towards the diagonals its path can reach (end diagonal m - L): deletion-only,
     insertion-only and long contiguous gaps put the path far from the main diagonal, and the rates make the
-    distances straddle every band-class limit (54, 118, 246, 502)."""
+    distances straddle every band-class limit (54, 118, 246, 374)."""
     rng = np.random.RandomState(13 + int(mix[0] * 10) + int(mix[2] * 100))
     for qr, tr, n, rates, block in [((9, 260), (100, 900), 1200, (0.05, 0.2, 0.3, 0.38), 0),
                                     ((100, 400), (300, 1000), 500, (0.1, 0.2, 0.3), 60),

@@ -27,7 +27,11 @@
 namespace {
 
 enum { MODE_FWD = 0, MODE_FWD_EXACT = 1, MODE_REV = 2, MODE_NW = 3 };
-enum { kBandClasses = 4, kBandFallback = 4 }; // banded traceback: WB = 1, 2, 4, 8 words; class 4 = not banded
+enum { kBandClasses = 4, kBandFallback = 4 }; // banded traceback: WB = 1, 2, 4, 6 words; class 4 = not banded
+// A lane-per-hit band kernel is bound by its longest lane (words x columns, twice): 6 words cover all but a
+// handful of hits per batch, and those few are quicker through the lane-group full-height kernels than through
+// an 8-word band.
+__host__ __device__ constexpr int band_words(int c) { return c < 2 ? c + 1 : c == 2 ? 4 : 6; }
 
 struct MyArgs {
     const uint8_t *seq, *rseq;
@@ -742,7 +746,8 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
     const int64_t lo = a.loc_off[p];
     const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
     // ed + 1 diagonals, one spare on either side, up to 7 lost to the window's 8-row alignment: ed <= 64 WB - 10
-    const uint32_t c = ed <= 54 ? 0 : ed <= 118 ? 1 : ed <= 246 ? 2 : ed <= 502 ? 3 : kBandFallback;
+    uint32_t c = 0;
+    while (c < kBandFallback && ed > 64 * band_words((int)c) - 10) c++;
     if (c < kBandFallback) keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
     else keys[i] = (c << kBandLBits) | (size_class_of(a.q_len[p]) << kFullLBits) | (((1u << kFullLBits) - 1u) - (L < (1u << kFullLBits) ? L : (1u << kFullLBits) - 1u));
 }
@@ -1274,7 +1279,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         int64_t units[kBandClasses], region[kBandClasses];
         size_t total_words = 0;
         for (int c = 0; c < kBandClasses; c++) {
-            const int WB = 1 << c;
+            const int WB = band_words(c);
             const int K = WB <= 1 ? 16 : 8;
             units[c] = region[c] = 0;
             if (h_band[c] <= 0) continue;
@@ -1300,24 +1305,21 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             const dim3 grid((unsigned)units[c]), block(64);
             hipStream_t cs = ctx->lane(c);
             const int64_t ni = h_band[c];
-            const size_t band_lds = (size_t)(c == 0 ? 16 : c == 1 ? 16 : c == 2 ? 32 : 64) * 64 * sizeof(ulonglong2); // K * WB columns-words
-            if (band_lds > 64 * 1024) {
-                ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)myers_band<8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
-                ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)myers_band<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
-            }
+            const int WB = band_words(c);
+            const size_t band_lds = (size_t)(WB <= 1 ? 16 : 8) * WB * 64 * sizeof(ulonglong2); // K columns x WB words per lane
             if (np == 3) {
-                switch (c) {
-                case 0: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, band_lds, cs, b, items, ni); break;
-                case 1: hipLaunchKernelGGL((myers_band<2, 3>), grid, block, band_lds, cs, b, items, ni); break;
-                case 2: hipLaunchKernelGGL((myers_band<4, 3>), grid, block, band_lds, cs, b, items, ni); break;
-                default: hipLaunchKernelGGL((myers_band<8, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                switch (WB) {
+                case 1: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_band<2, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                case 4: hipLaunchKernelGGL((myers_band<4, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                default: hipLaunchKernelGGL((myers_band<6, 3>), grid, block, band_lds, cs, b, items, ni); break;
                 }
             } else {
-                switch (c) {
-                case 0: hipLaunchKernelGGL((myers_band<1, 5>), grid, block, band_lds, cs, b, items, ni); break;
-                case 1: hipLaunchKernelGGL((myers_band<2, 5>), grid, block, band_lds, cs, b, items, ni); break;
-                case 2: hipLaunchKernelGGL((myers_band<4, 5>), grid, block, band_lds, cs, b, items, ni); break;
-                default: hipLaunchKernelGGL((myers_band<8, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                switch (WB) {
+                case 1: hipLaunchKernelGGL((myers_band<1, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_band<2, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                case 4: hipLaunchKernelGGL((myers_band<4, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                default: hipLaunchKernelGGL((myers_band<6, 5>), grid, block, band_lds, cs, b, items, ni); break;
                 }
             }
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
