@@ -261,7 +261,7 @@ def main():
                 except Exception:
                     traffic = fam_traffic = None
             # The forward pass is ONE kernel template instantiated per register bucket; the (up to 5) instantiations
-            # of a step are launched together on 4 streams and share the CUs, so the duration of a single one says
+            # of a step are launched together on their own streams and share the CUs, so the duration of a single one says
             # how long it shared the chip, not how fast it is.  The roofline is therefore taken over the family:
             # all forward cells of the step / (first launch start -> last launch end, HIP events on those streams).
             # The largest single instantiation, whose avg duration is the one rocprofv3 --stats lists, is kept below.
@@ -271,6 +271,11 @@ def main():
                     "achieved": fam_ach, "peak": peak_ops * 1e-12, "unit": "Tops/s", "frac": fam_ach / (peak_ops * 1e-12),
                     "traffic": fam_traffic, "cells_per_launch": cells_all / world, "avg_launch_ms": fam_ms,
                     "ops_per_cell": OPS_PER_CELL,
+                    # profiles/r01_valu_issue_rate.txt: a SIMD issues one plain 32-bit VALU instruction per 2.44 cycles of
+                    # the nominal 2.4 GHz under this kind of load (the chip down-clocks), three-source ALU ops
+                    # (v_alignbit / v_lshl_or / v_add3) and 64-bit adds per 4.2
+                    "peak_sustained_measured": peak_ops * 1e-12 * 2.0 / 2.44,
+                    "frac_of_sustained": fam_ach / (peak_ops * 1e-12 * 2.0 / 2.44),
                     "largest_instantiation": {"kernel": kname, "achieved": achieved, "frac": achieved / (peak_ops * 1e-12),
                                               "traffic": traffic, "cells_per_launch": c / launches, "avg_launch_ms": ms / launches,
                                               "note": "runs concurrently with the other buckets' launches"},
