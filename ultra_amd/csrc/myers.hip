@@ -47,6 +47,7 @@ struct MyArgs {
     uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
     int64_t begin, end;
     int32_t *wflag; // per work item of a forward launch: some pair has more end columns than first-pass slots
+    int32_t nbb;    // lane-group traceback: 64-row blocks stored per column (the ones the path's band crosses); 0 = all
 };
 
 struct Item {
@@ -170,10 +171,20 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // the target is used up only insertions remain.
 constexpr int kStage = 8; // columns (x 2 words) staged in LDS per refill of the walk
 
+// Columns may hold only nbb of the nwords blocks: those from first(c) = clamp((c + lo_pad) >> 6, 0, nwords - nbb) on
+// (lo_pad = lowest reachable diagonal - 1 + pad); nbb == nwords is the full-height layout.
 __device__ __forceinline__ void traceback(const ulonglong2 *tr, int64_t stride, int64_t colstride, int pad, int rows, int L,
                                           const uint8_t *q, const uint8_t *t, uint8_t *ops, int ops_cap, int &n_ins, int &n_ops,
-                                          ulonglong2 *stage)
+                                          ulonglong2 *stage, int nbb, int lo_pad)
 {
+    auto at = [&](int ck, int w) {
+        int f = (ck + lo_pad) >> 6;
+        const int fmax = (rows >> 6) - nbb;
+        f = f < 0 ? 0 : f > fmax ? fmax : f;
+        int rel = w - f;
+        rel = rel < 0 ? 0 : rel >= nbb ? nbb - 1 : rel; // blocks a staged column does not hold are never walked
+        return (int64_t)ck * colstride + (int64_t)rel * stride;
+    };
     // The walk goes through the columns backwards: kStage columns x 2 adjacent words around the
     // current row are staged per refill (all loads in flight together) instead of one dependent
     // HBM load per step.  stage: this lane's slots at stage[i * 64].
@@ -192,8 +203,8 @@ __device__ __forceinline__ void traceback(const ulonglong2 *tr, int64_t stride, 
 #pragma unroll
             for (int k = 0; k < kStage; k++) {
                 const int ck = c - k > 0 ? c - k : 0;
-                buf[2 * k] = tr[(int64_t)ck * colstride + (int64_t)wlo * stride];
-                buf[2 * k + 1] = tr[(int64_t)ck * colstride + (int64_t)w1 * stride];
+                buf[2 * k] = tr[at(ck, wlo)];
+                buf[2 * k + 1] = tr[at(ck, w1)];
             }
 #pragma unroll
             for (int k = 0; k < kStage * 2; k++) stage[k * 64] = buf[k];
@@ -344,7 +355,7 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
                 if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
                 int ins, nops;
                 traceback(tT, 64, (int64_t)W * 64, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops,
-                          (ulonglong2 *)(lds_wave + (size_t)S * W * 64) + lane);
+                          (ulonglong2 *)(lds_wave + (size_t)S * W * 64) + lane, W, 0);
                 a.first_ins[it.pair] = ins;
                 if (a.n_ops) a.n_ops[it.pair] = nops;
             }
@@ -407,6 +418,15 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
         ulonglong2 *tT = nullptr;
         if (MODE == MODE_NW) tT = a.tr + (slot0 + p) * a.region;
+        // NW pass with a known distance: only the blocks that the ed + 1 reachable diagonals cross are stored
+        // (myers_band explains the range); nbb == NB stores everything.
+        const int nbb = (MODE == MODE_NW && a.nbb > 0 && a.nbb < NB) ? a.nbb : NB;
+        int lo_pad = 0;
+        if (MODE == MODE_NW) {
+            const int delta = it.m - it.n;
+            const int hh = (it.best - (delta < 0 ? -delta : delta)) >> 1;
+            lo_pad = (delta < 0 ? delta : 0) - hh - 1 + pad;
+        }
         const int n = it.valid ? it.n : 0;
         const int nmax = wave_max_i32(n);
         const int steps = nmax + G - 1;
@@ -431,7 +451,10 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                     word_step(Pv[w], Mv[w], pe[w], hp, hm, ph0);
                     if (MODE == MODE_NW) {
                         ulonglong2 e; e.x = Pv[w]; e.y = ph0;
-                        tT[(int64_t)col * NB + g * W + w] = e;
+                        int f = (col + lo_pad) >> 6;
+                        f = f < 0 ? 0 : f > NB - nbb ? NB - nbb : f;
+                        const int rel = g * W + w - f;
+                        if (rel >= 0 && rel < nbb) tT[(int64_t)col * nbb + rel] = e;
                     }
                 }
                 h_out = hp | (hm << 1);
@@ -461,8 +484,8 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                 uint8_t *ops = nullptr; int ops_cap = 0;
                 if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
                 int ins, nops;
-                traceback(tT, 1, (int64_t)NB, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops,
-                          (ulonglong2 *)(lds_wave + (size_t)S * NB * P) + lane);
+                traceback(tT, 1, (int64_t)nbb, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops,
+                          (ulonglong2 *)(lds_wave + (size_t)S * NB * P) + lane, nbb, lo_pad);
                 a.first_ins[it.pair] = ins;
                 if (a.n_ops) a.n_ops[it.pair] = nops;
             }
@@ -737,7 +760,8 @@ __device__ __forceinline__ uint32_t size_class_of(int m)
     return m <= 256 ? (uint32_t)((m - 1) >> 6) : m <= 384 ? 4u : m <= 512 ? 5u : m <= 768 ? 6u : m <= 1024 ? 7u : m <= 1536 ? 8u
          : m <= 2048 ? 9u : m <= 4096 ? 10u : m <= 8192 ? 11u : m <= 16384 ? 12u : 13u;
 }
-__global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys)
+// edmax[size class] = largest distance among the hits no band class takes (sizes the stored band of the lane-group kernels)
+__global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys, int32_t *edmax)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
@@ -749,7 +773,11 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
     uint32_t c = 0;
     while (c < kBandFallback && ed > 64 * band_words((int)c) - 10) c++;
     if (c < kBandFallback) keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
-    else keys[i] = (c << kBandLBits) | (size_class_of(a.q_len[p]) << kFullLBits) | (((1u << kFullLBits) - 1u) - (L < (1u << kFullLBits) ? L : (1u << kFullLBits) - 1u));
+    else {
+        const uint32_t sc = size_class_of(a.q_len[p]);
+        keys[i] = (c << kBandLBits) | (sc << kFullLBits) | (((1u << kFullLBits) - 1u) - (L < (1u << kFullLBits) ? L : (1u << kFullLBits) - 1u));
+        atomicMax(&edmax[sc], ed);
+    }
 }
 // info[g] = first sorted position of group g (band classes 0..3, then the 14 size classes of the
 // rest, then the end); info[kBandBounds + c] = longest first location of band class c
@@ -1241,8 +1269,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0;
     a.nw_items = nullptr;
     bool forked = false;
-    int32_t full_first[kNumSizeClasses + 1];
+    int32_t full_first[kNumSizeClasses + 1], full_edmax[kNumSizeClasses];
     for (auto &v : full_first) v = 0;
+    for (auto &v : full_edmax) v = 0;
     const int32_t *d_items_sorted = nullptr;
     if (use_band) {
         // 3a: banded kernels for every hit whose distance fits a band of at most 512 rows
@@ -1253,7 +1282,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         uint32_t *k_in = st.banditems.as<uint32_t>(), *k_out = k_in + NH;
         int32_t *items_sorted = (int32_t *)(k_out + NH);
         const unsigned gb = (unsigned)((n_hits + 255) / 256);
-        hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in);
+        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bandinfo.p, 0, 256, s));
+        hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in, st.bandinfo.as<int32_t>() + kBandBounds + kBandClasses);
         {
             size_t tmp_bytes = 0;
             ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 3, s));
@@ -1262,7 +1292,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         }
         hipLaunchKernelGGL(k_band_bounds, dim3(1), dim3(64), 0, s, k_out, n_hits, st.bandinfo.as<int32_t>());
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
-        int32_t h_info[kBandBounds + kBandClasses];
+        int32_t h_info[kBandBounds + kBandClasses + kNumSizeClasses];
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, sizeof h_info, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         int32_t band_first[kBandClasses + 1];
@@ -1273,6 +1303,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         }
         h_band[kBandFallback] = h_info[kBandBounds - 1] - h_info[kBandClasses];
         for (int c = 0; c <= kNumSizeClasses; c++) full_first[c] = h_info[kBandClasses + c];
+        for (int c = 0; c < kNumSizeClasses; c++) full_edmax[c] = h_info[kBandBounds + kBandClasses + c];
         d_items_sorted = items_sorted;
         const int np = st.S + 1 <= 8 ? 3 : 5; // bit-planes of (code + 1)
         // checkpoint scratch (64-bit words), split between the band classes so that their launches can overlap
@@ -1330,7 +1361,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     //     each other and with the banded ones (these are bound by their critical path, not by the ALUs).
     const bool need_full = !use_band || h_band[kBandFallback] > 0;
     if (need_full) {
-        struct FullPlan { int cls; int64_t region, items, begin, end, Lmax; int max_par; size_t entries; };
+        struct FullPlan { int cls; int64_t region, items, begin, end, Lmax; int max_par; size_t entries; int nbb; };
         std::vector<FullPlan> plans;
         for (auto &mc : st.classes) {
             if (mc.he <= mc.hb) continue;
@@ -1350,6 +1381,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             // first location: L = end - start + 1 <= m + ed <= m + k, and k <= m (clamped in setup_item)
             fp.Lmax = std::min<int64_t>(max_t, (int64_t)2 * 64 * NB);
             const size_t share = budget / plans.size();
+            fp.nbb = 0;
             if (G == 1) {
                 fp.region = fp.Lmax * W * 64;
                 int64_t waves = (fp.items + 63) / 64;
@@ -1359,7 +1391,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
                 fp.entries = (size_t)fp.region * (size_t)(units + 4); // the grid is rounded up to whole blocks
             } else {
                 const int P = 64 / G;
-                fp.region = fp.Lmax * NB;
+                // distance known (banded mode): blocks crossed by ed + 3 diagonals, + 1 for their alignment
+                fp.nbb = use_band ? std::min<int>(NB, (full_edmax[fp.cls] + 3 + 63) / 64 + 1) : NB;
+                fp.region = fp.Lmax * fp.nbb;
                 int64_t blocks = (fp.items + P - 1) / P;
                 int64_t b = std::min<int64_t>(blocks, std::max<int64_t>(1, (int64_t)(share / (size_t)(fp.region * 16 * P))));
                 b = std::min<int64_t>(b, (int64_t)ctx->prop.multiProcessorCount * 32);
@@ -1376,7 +1410,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             MyArgs b = a;
             b.tr = st.trace2.as<ulonglong2>() + at;
             at += it->entries;
-            b.region = it->region; b.Lmax = (int32_t)it->Lmax;
+            b.region = it->region; b.Lmax = (int32_t)it->Lmax; b.nbb = it->nbb;
             b.begin = it->begin; b.end = it->end;
             b.nw_items = use_band ? d_items_sorted : nullptr;
             ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->lane(kBandClasses + q), it->cls, b, it->items, it->max_par));
