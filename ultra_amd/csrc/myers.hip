@@ -497,6 +497,7 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
 template <int G, int W, int MODE>
 __global__ void __launch_bounds__(64) myers_group(MyArgs a)
 {
+    if (MODE == MODE_NW) __builtin_amdgcn_s_setprio(3); // few, long wavefronts beside the band kernels (see myers_band)
     extern __shared__ uint64_t lds[];
     constexpr int P = 64 / G;
     for (int64_t base = a.begin + (int64_t)blockIdx.x * P; base < a.end; base += (int64_t)gridDim.x * P)
@@ -566,6 +567,9 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
     constexpr int TOP = 32 * WB - 1;
     constexpr int K = BandK<WB>::K;
     constexpr int CPW = (2 + NP) * WB; // 64-bit words per checkpoint and lane
+    // The traceback launches are bound by their longest wavefronts, the wider the band the longer: let those win
+    // the issue slots of a SIMD they share with the many short wavefronts of the narrow classes.
+    __builtin_amdgcn_s_setprio(WB >= 6 ? 3 : WB >= 4 ? 2 : WB >= 2 ? 1 : 0);
     const int lane = threadIdx.x;
     const int64_t gwave = blockIdx.x, nwaves = gridDim.x;
     uint64_t *CP = (uint64_t *)a.tr + gwave * a.region + lane; // checkpoint (chunk h, word f) at CP[(h * CPW + f) * 64]
