@@ -226,6 +226,57 @@ int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out);
  * [0] MAM materialisation, [1] chaining, [2] chain compaction. */
 int ultra_mam_last_timing(const ultra_ctx *ctx, float ms[3]);
 
+/*
+ * Packed index + candidate enumeration on the host.  No GPU work: these calls build,
+ * natively and for a whole batch, the ultra_mam_input that ultra_mam_stage takes.  They replace the dictionary part
+ * of classify_read_with_mams.main (modules/classify_read_with_mams.py:406-523): get_unique_exon_and_flank_locations
+ * (:180-253), get_unique_segment_and_flank_choordinates (:256-300), the candidate loops and the edlib call shapes
+ * (:303-377, :441-523), over flat copies of the five index dictionaries a worker unpickles (modules/align.py:53-110).
+ *
+ * Index: every key is the triple (chromosome id, start, stop) the reference packs with array('L', ...).tobytes().
+ *   parts_to_segments        part_key[3*n_parts], CSR part_seg_off -> part_seg triples, in the stored order
+ *   segment_to_gene          seg_gene_key[3*n_seg_gene], CSR seg_gene_off -> dense gene numbers 0..n_genes-1
+ *   gene_to_small_segments   CSR gene_small_off[n_genes+1] -> gene_small triples
+ *   ref_segment_sequences / ref_flank_sequences   keys + offsets (n+1) into pool
+ * The index is copied; the caller's arrays may go away after the call.
+ */
+typedef struct ultra_index ultra_index;
+typedef struct ultra_index_input {
+    int64_t n_parts; const int64_t *part_key, *part_seg_off, *part_seg;
+    int64_t n_seg_gene; const int64_t *seg_gene_key, *seg_gene_off; const int32_t *seg_gene;
+    int64_t n_genes; const int64_t *gene_small_off, *gene_small;
+    int64_t n_seg_seq; const int64_t *seg_seq_key, *seg_seq_off;
+    int64_t n_flank_seq; const int64_t *flank_seq_key, *flank_seq_off;
+    const uint8_t *pool; int64_t pool_len;
+} ultra_index_input;
+int ultra_index_create(const ultra_index_input *in, ultra_index **out);
+void ultra_index_destroy(ultra_index *idx);
+
+/*
+ * One batch of (NAM chain, read) instances: instance i owns NAMs inst_nam_off[i] .. inst_nam_off[i+1]) in chain order
+ * (nam_part = the (chromosome, start, stop) of the NAM's exon_part_id "chr^start^stop", nam_x / nam_y its reference
+ * interval) and the read bytes reads[read_off[i] .. read_off[i+1]).
+ * The plan owns the arrays behind ultra_plan_input(); hand that pointer to ultra_mam_stage / ultra_mam_batch.
+ * ultra_plan_cands: per candidate the chromosome id of its MAMs and the chromosome field of its segment identifier
+ * (mam_id = str(pack('LLL', ident_chr, e_start, e_stop)) + label, or "flank_<start>_<stop>" + label), and the
+ * forward-pass cell count of the batch.  A candidate whose segment has no gene / no sequence in the index is the
+ * reference's KeyError: ULTRA_E_ARG, text from ultra_plan_last_error() (thread-local).
+ * Where the reference's order depends on the iteration order of a Python set (equal segment starts within one
+ * instance - does not occur for canonical segments) the order here is (start, stop, chromosome).
+ */
+typedef struct ultra_plan ultra_plan;
+typedef struct ultra_plan_request {
+    int32_t n_inst;
+    const int64_t *inst_nam_off;
+    const int64_t *nam_part, *nam_x, *nam_y;
+    const uint8_t *reads; const int64_t *read_off;
+} ultra_plan_request;
+int ultra_plan_create(const ultra_index *idx, const ultra_plan_request *rq, ultra_plan **out);
+const ultra_mam_input *ultra_plan_input(const ultra_plan *plan);
+int ultra_plan_cands(const ultra_plan *plan, const int32_t **chr, const int32_t **ident_chr, double *cells);
+void ultra_plan_destroy(ultra_plan *plan);
+const char *ultra_plan_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,3 +159,26 @@ def test_bad_candidate_lists_fail_loudly(ctx):
     bad["cand_kind"] = batch.packed["cand_kind"].copy(); bad["cand_kind"][0] = 3
     with pytest.raises(lib.UltraError):
         ctx.mam_stage(bad)
+
+
+@pytest.mark.parametrize("preset", ["ont_cdna", "ont_drna"])
+def test_native_plan_gives_the_same_results(ctx, preset):
+    """Row f4: the batch planned inside the library (packed index) goes through the same device stage and returns
+    the same tuples - names, chromosome ids, values, gaps - as the batch planned by the Python port."""
+    from ultra_amd import index as native
+    w = synth.make_world(seed=41, n_genes=50)
+    idx = w.index()
+    insts = synth.make_instances(w, 200, seed=12, preset=preset, flank_start_prob=0.3, flank_end_prob=0.3)
+    pairs = [(sol, read) for read, sol, _ in insts]
+    min_acc = synth.PRESETS[preset]["min_acc"]
+    want = hip_stage.main_batch(pairs, *idx, min_acc=min_acc, ctx=ctx)
+    ix = native.NativeIndex(*idx)
+    try:
+        got = hip_stage.main_batch(pairs, *idx, min_acc=min_acc, ctx=ctx, index=ix)
+    finally:
+        ix.close()
+    assert len(got) == len(want)
+    for g, w_ in zip(got, want):
+        assert g[0] == w_[0]
+        assert struct.pack("d", float(g[1])) == struct.pack("d", float(w_[1]))
+        assert tuple(tuple(m) for m in g[2]) == tuple(tuple(m) for m in w_[2])

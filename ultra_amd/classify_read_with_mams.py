@@ -243,9 +243,18 @@ def prepare_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_t
                        for solution, read_seq in instances])
 
 
+def prepare_batch_native(index, instances):
+    """The same batch built inside libultra_hip.so from a packed index (ultra_amd.index.NativeIndex, SURVEY.md
+    section 8 row f4): no Python object per candidate."""
+    return index.plan(instances)
+
+
 def stage_batch(ctx, batch):
     """Host -> HBM copy of the packed batch (once; run_staged may repeat)."""
-    ctx.mam_stage(batch.packed)
+    if hasattr(batch, "handle"):
+        ctx.mam_stage_plan(batch)
+    else:
+        ctx.mam_stage(batch.packed)
 
 
 def run_staged(ctx, min_acc):
@@ -263,24 +272,40 @@ def _mam_tuple(plan, res, prefix, r, j, cand_base):
                val, j, msl, str(cand.ident) + LABELS[cand.kind], cand.chr_id)
 
 
+def _mam_tuple_native(batch, res, prefix, r, j):
+    ci = int(res[prefix + "cand"][r])
+    msl = int(res[prefix + "msl"][r])
+    val = float(res[prefix + "val"][r])
+    if msl == 0:
+        val = int(val)
+    return mam(int(res[prefix + "x"][r]), int(res[prefix + "y"][r]), int(res[prefix + "c"][r]), int(res[prefix + "d"][r]),
+               val, j, msl, batch.mam_id(ci, LABELS[int(batch.packed["cand_kind"][ci])]), int(batch.cand_chr[ci]))
+
+
 def results_to_python(batch, res):
     """(non_covered_regions, value, mam_solution) per instance from the fetched arrays (:577-594).
     The j of a chain element is its index in the instance's sorted MAM list, as in the reference."""
     out = []
     coff = batch.packed["inst_cand_off"]
     j_of = res.get("chain_j")
-    for i, plan in enumerate(batch.plans):
+    native = hasattr(batch, "handle")
+    for i in range(batch.n_inst):
         if int(res["n_mam"][i]) == 0:
             out.append(([], -1, tuple()))
             continue
         a, b = int(res["chain_off"][i]), int(res["chain_off"][i + 1])
-        picked = tuple(_mam_tuple(plan, res, "chain_", r, int(j_of[r]), int(coff[i])) for r in range(a, b))
+        if native:
+            picked = tuple(_mam_tuple_native(batch, res, "chain_", r, int(j_of[r])) for r in range(a, b))
+            read_len = batch.reads[i]
+        else:
+            picked = tuple(_mam_tuple(batch.plans[i], res, "chain_", r, int(j_of[r]), int(coff[i])) for r in range(a, b))
+            read_len = len(batch.plans[i].read)
         gaps = []
         if picked:
             gaps.append(picked[0].c)
             for p, q in zip(picked[:-1], picked[1:]):
                 gaps.append(q.c - p.d - 1)
-            gaps.append(len(plan.read) - picked[-1].d)
+            gaps.append(read_len - picked[-1].d)
         out.append((gaps, float(res["value"][i]), picked))
     return out
 
@@ -296,12 +321,17 @@ def mam_lists_to_python(batch, res):
 
 
 def main_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
-               gene_to_small_segments, min_acc, ctx=None, stats=None):
+               gene_to_small_segments, min_acc, ctx=None, stats=None, index=None):
     """instances: iterable of (solution, read_seq). Returns one (non_covered_regions, value,
-    mam_solution) per instance, equal to what the reference's main() returns for each."""
+    mam_solution) per instance, equal to what the reference's main() returns for each.
+    index: an ultra_amd.index.NativeIndex built once from the same five dictionaries - the batch is then planned
+    natively (the dictionaries themselves are not read)."""
     ctx = ctx or _lib.default_context()
-    batch = prepare_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
-                          gene_to_small_segments)
+    if index is not None:
+        batch = prepare_batch_native(index, list(instances))
+    else:
+        batch = prepare_batch(instances, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene,
+                              gene_to_small_segments)
     if batch.n_inst == 0:
         return []
     stage_batch(ctx, batch)

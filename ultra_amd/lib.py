@@ -22,6 +22,8 @@ EXPORTS = [
     "ultra_device_info", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
     "ultra_myers_last_timing", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
+    "ultra_index_create", "ultra_index_destroy", "ultra_plan_create", "ultra_plan_input", "ultra_plan_cands",
+    "ultra_plan_destroy", "ultra_plan_last_error",
 ]
 
 
@@ -58,6 +60,22 @@ class MamOutput(C.Structure):
                 ("mam_cap", C.c_int64), ("mam_off", _I64P),
                 ("mam_x", _I32P), ("mam_y", _I32P), ("mam_c", _I32P), ("mam_d", _I32P), ("mam_val", _F64P),
                 ("mam_msl", _I32P), ("mam_cand", _I32P)]
+
+
+class IndexInput(C.Structure):
+    """ultra_index_input (include/ultra_hip.h)."""
+    _fields_ = [("n_parts", C.c_int64), ("part_key", _I64P), ("part_seg_off", _I64P), ("part_seg", _I64P),
+                ("n_seg_gene", C.c_int64), ("seg_gene_key", _I64P), ("seg_gene_off", _I64P), ("seg_gene", _I32P),
+                ("n_genes", C.c_int64), ("gene_small_off", _I64P), ("gene_small", _I64P),
+                ("n_seg_seq", C.c_int64), ("seg_seq_key", _I64P), ("seg_seq_off", _I64P),
+                ("n_flank_seq", C.c_int64), ("flank_seq_key", _I64P), ("flank_seq_off", _I64P),
+                ("pool", _U8P), ("pool_len", C.c_int64)]
+
+
+class PlanRequest(C.Structure):
+    """ultra_plan_request (include/ultra_hip.h)."""
+    _fields_ = [("n_inst", C.c_int32), ("inst_nam_off", _I64P), ("nam_part", _I64P), ("nam_x", _I64P), ("nam_y", _I64P),
+                ("reads", _U8P), ("read_off", _I64P)]
 
 
 _lib = None
@@ -98,6 +116,17 @@ def load():
     lib.ultra_mam_sizes.argtypes = [vp, i64p, i64p]
     lib.ultra_mam_fetch.argtypes = [vp, C.POINTER(MamOutput)]
     lib.ultra_mam_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ultra_index_create.argtypes = [C.POINTER(IndexInput), C.POINTER(vp)]
+    lib.ultra_index_destroy.argtypes = [vp]
+    lib.ultra_index_destroy.restype = None
+    lib.ultra_plan_create.argtypes = [vp, C.POINTER(PlanRequest), C.POINTER(vp)]
+    lib.ultra_plan_input.argtypes = [vp]
+    lib.ultra_plan_input.restype = C.POINTER(MamInput)
+    lib.ultra_plan_cands.argtypes = [vp, C.POINTER(i32p), C.POINTER(i32p), f64p]
+    lib.ultra_plan_destroy.argtypes = [vp]
+    lib.ultra_plan_destroy.restype = None
+    lib.ultra_plan_last_error.argtypes = []
+    lib.ultra_plan_last_error.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -259,6 +288,12 @@ class Context(object):
         inp.n_inst = len(keep["inst_read_len"])
         self._mam_n_inst = inp.n_inst
         self._check(self.lib.ultra_mam_stage(self._h, C.byref(inp)))
+
+    def mam_stage_plan(self, plan):
+        """plan: ultra_amd.index.NativePlan - its ultra_mam_input goes to the device as it is (no numpy round trip)."""
+        inp = self.lib.ultra_plan_input(plan.handle)
+        self._mam_n_inst = int(inp.contents.n_inst)
+        self._check(self.lib.ultra_mam_stage(self._h, inp))
 
     def mam_run(self, min_acc):
         self._check(self.lib.ultra_mam_run(self._h, float(min_acc)))
