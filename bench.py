@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--stagger-ms", type=float, default=4.0, help="start offset between the contexts' loops (--contexts > 1)")
     ap.add_argument("--lanes", type=int, default=0, help="launch lanes (HIP streams) per context, 0 = library default (4)")
     ap.add_argument("--slots", type=int, default=0, help="end positions kept per pair in the first pass, 0 = library default")
+    ap.add_argument("--planner", default="native", choices=["native", "python"],
+                    help="host-side candidate enumeration: packed index + csrc/plan.hip, or the Python port")
     ap.add_argument("--check", type=int, default=64, help="instances of the last step verified against the oracle")
     return ap.parse_args()
 
@@ -106,7 +108,16 @@ def main():
     w = synth.make_world(seed=20241008, n_genes=args.genes, n_chr=8)
     idx = w.index()
     insts = synth.make_instances(w, args.reads, seed=1000 + rank, preset=args.preset)
-    batch = stage.prepare_batch([(sol, read) for read, sol, _ in insts], *idx)
+    import torch  # noqa: F401  (before libultra_hip.so is loaded: both must end up on the same HIP runtime - torch's)
+    t_plan = time.perf_counter()
+    if args.planner == "native" and args.contexts <= 1:
+        from ultra_amd import index as native_index
+        nix = native_index.NativeIndex(*idx)
+        t_plan = time.perf_counter()
+        batch = nix.plan([(sol, read) for read, sol, _ in insts])
+    else:
+        batch = stage.prepare_batch([(sol, read) for read, sol, _ in insts], *idx)
+    plan_s = time.perf_counter() - t_plan
     cells = batch.cells
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -296,7 +307,8 @@ def main():
             "stage_ms_per_step": {"myers_forward": fwd_ms / K, "myers_starts": rev_ms / K, "myers_traceback": tb_ms / K,
                                   "myers_total": all_ms / K, "mam_build": build_ms / K, "chain": chain_ms / K,
                                   "chain_gather": gather_ms / K},
-            "outside_timed_region": {"fetch_results_pcie_ms": fetch_s * 1e3, "python_tuples_ms": topy_s * 1e3,
+            "outside_timed_region": {"host_plan_us_per_read": plan_s / len(insts) * 1e6, "host_planner": args.planner if args.contexts <= 1 else "python",
+                                     "fetch_results_pcie_ms": fetch_s * 1e3, "python_tuples_ms": topy_s * 1e3,
                                      "reads_per_s_incl_fetch": reads_all / world / (elapsed / K + fetch_s),
                                      "chain_rows_fetched": int(res["chain_off"][-1])},
             "forward_buckets": {"bucket%d_wmax%d" % k: {"cells_per_step": v[0] / v[2], "ms_per_step": v[1] / v[2],

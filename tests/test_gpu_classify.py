@@ -165,7 +165,9 @@ def test_bad_candidate_lists_fail_loudly(ctx):
 def test_native_plan_gives_the_same_results(ctx, preset):
     """Row f4: the batch planned inside the library (packed index) goes through the same device stage and returns
     the same tuples - names, chromosome ids, values, gaps - as the batch planned by the Python port."""
+    from ultra_amd import classify_read_with_mams as hip_stage
     from ultra_amd import index as native
+    from ultra_amd import synth
     w = synth.make_world(seed=41, n_genes=50)
     idx = w.index()
     insts = synth.make_instances(w, 200, seed=12, preset=preset, flank_start_prob=0.3, flank_end_prob=0.3)

@@ -99,12 +99,14 @@ struct Cand {
     Slice seq; // into the index pool
 };
 
-// arena of one batch: every distinct (pool slice | read) once, pairs de-duplicated by (query, target, k)
+// arena of one batch: every distinct (pool slice | read) once, pairs de-duplicated by (query, target, k).  A pair
+// contains its instance's read, so equal pairs can only meet inside one instance: a short linear list, no hashing.
 struct PairTable {
     ultra_plan &p;
     std::unordered_map<Key3, int64_t, Key3Hash> where;  // {source tag, offset, length} -> arena offset
-    std::unordered_map<std::string, int32_t> pair_of;
+    size_t inst_first = 0;                              // first pair of the current instance
     explicit PairTable(ultra_plan &pl) : p(pl) {}
+    void next_instance() { inst_first = p.k.size(); }
     int64_t put(int64_t tag, int64_t off, int64_t len, const uint8_t *bytes)
     {
         const Key3 key{tag, off, len};
@@ -117,16 +119,13 @@ struct PairTable {
     }
     int32_t add(int64_t qo, int64_t ql, int64_t to, int64_t tl, int32_t kk)
     {
-        int64_t raw[5] = {qo, ql, to, tl, kk};
-        std::string key((const char *)raw, sizeof raw);
-        auto it = pair_of.find(key);
-        if (it != pair_of.end()) return it->second;
+        for (size_t i = inst_first; i < p.k.size(); i++)
+            if (p.q_off[i] == qo && p.t_off[i] == to && p.q_len[i] == ql && p.t_len[i] == tl && p.k[i] == kk) return (int32_t)i;
         const int32_t id = (int32_t)p.k.size();
         p.q_off.push_back(qo); p.q_len.push_back((int32_t)ql);
         p.t_off.push_back(to); p.t_len.push_back((int32_t)tl);
         p.k.push_back(kk);
         p.cells += (double)ql * (double)tl;
-        pair_of.emplace(std::move(key), id);
         return id;
     }
 };
@@ -180,6 +179,15 @@ extern "C" int ultra_plan_create(const ultra_index *ix, const ultra_plan_request
     if (rq->n_inst < 0) return plan_fail(ULTRA_E_ARG, "ultra_plan_create: negative instance count");
     ultra_plan *pl = new ultra_plan();
     PairTable pairs(*pl);
+    {
+        const size_t ni = (size_t)rq->n_inst, nc = ni * 24, np = ni * 20;
+        pairs.where.reserve(np);
+        pl->arena.reserve((size_t)(rq->n_inst > 0 ? rq->read_off[rq->n_inst] - rq->read_off[0] : 0) + np * 160);
+        for (auto *v : {&pl->q_len, &pl->t_len, &pl->k}) v->reserve(np);
+        pl->q_off.reserve(np); pl->t_off.reserve(np);
+        for (auto *v : {&pl->e_start, &pl->e_stop, &pl->pair, &pl->pair_contained, &pl->seq_len, &pl->seq_id, &pl->chr, &pl->ident_chr}) v->reserve(nc);
+        pl->kind.reserve(nc);
+    }
     pl->cand_off.push_back(0);
     std::vector<Loc> seg_hits, flank_hits, full_order, flank_order;
     std::unordered_map<Key3, std::pair<int64_t, int64_t>, Key3Hash> seg_span, flank_span; // loc -> (first NAM's x, last NAM's y)
@@ -299,6 +307,7 @@ extern "C" int ultra_plan_create(const ultra_index *ix, const ultra_plan_request
         if (lr < 0) { delete pl; return plan_fail(ULTRA_E_ARG, "ultra_plan_create: read offsets not ascending"); }
         int64_t read_at = -1;
         const size_t first_cand = pl->kind.size();
+        pairs.next_instance();
         for (const Cand &c : cands) {
             int32_t pr = -1, prc = -1;
             const int64_t width = c.loc.s1 - c.loc.s0, ls = c.seq.len;
