@@ -272,41 +272,44 @@ def _mam_tuple(plan, res, prefix, r, j, cand_base):
                val, j, msl, str(cand.ident) + LABELS[cand.kind], cand.chr_id)
 
 
-def _mam_tuple_native(batch, res, prefix, r, j):
-    ci = int(res[prefix + "cand"][r])
-    msl = int(res[prefix + "msl"][r])
-    val = float(res[prefix + "val"][r])
-    if msl == 0:
-        val = int(val)
-    return mam(int(res[prefix + "x"][r]), int(res[prefix + "y"][r]), int(res[prefix + "c"][r]), int(res[prefix + "d"][r]),
-               val, j, msl, batch.mam_id(ci, LABELS[int(batch.packed["cand_kind"][ci])]), int(batch.cand_chr[ci]))
-
-
 def results_to_python(batch, res):
     """(non_covered_regions, value, mam_solution) per instance from the fetched arrays (:577-594).
-    The j of a chain element is its index in the instance's sorted MAM list, as in the reference."""
+    The j of a chain element is its index in the instance's sorted MAM list, as in the reference.
+    Works on plain lists (one .tolist() per array): indexing numpy scalars one by one costs several times more."""
     out = []
-    coff = batch.packed["inst_cand_off"]
-    j_of = res.get("chain_j")
     native = hasattr(batch, "handle")
+    coff = batch.packed["inst_cand_off"].tolist()
+    n_mam, chain_off, value = res["n_mam"].tolist(), res["chain_off"].tolist(), res["value"].tolist()
+    cx, cy, cc, cd = res["chain_x"].tolist(), res["chain_y"].tolist(), res["chain_c"].tolist(), res["chain_d"].tolist()
+    cval, cmsl, ccand, cj = res["chain_val"].tolist(), res["chain_msl"].tolist(), res["chain_cand"].tolist(), res["chain_j"].tolist()
+    if native:
+        kinds, chrs = batch.packed["cand_kind"].tolist(), batch.cand_chr.tolist()
+        names = {}
     for i in range(batch.n_inst):
-        if int(res["n_mam"][i]) == 0:
+        if n_mam[i] == 0:
             out.append(([], -1, tuple()))
             continue
-        a, b = int(res["chain_off"][i]), int(res["chain_off"][i + 1])
-        if native:
-            picked = tuple(_mam_tuple_native(batch, res, "chain_", r, int(j_of[r])) for r in range(a, b))
-            read_len = batch.reads[i]
-        else:
-            picked = tuple(_mam_tuple(batch.plans[i], res, "chain_", r, int(j_of[r]), int(coff[i])) for r in range(a, b))
-            read_len = len(batch.plans[i].read)
+        picked = []
+        for r in range(chain_off[i], chain_off[i + 1]):
+            ci, msl = ccand[r], cmsl[r]
+            val = int(cval[r]) if msl == 0 else cval[r]  # 5-8 bp exact segment: the reference stores the int len(exon_seq) (:357-367)
+            if native:
+                name = names.get(ci)
+                if name is None:
+                    name = names[ci] = batch.mam_id(ci, LABELS[kinds[ci]])
+                chr_id = chrs[ci]
+            else:
+                cand = batch.plans[i].cands[ci - coff[i]]
+                name, chr_id = str(cand.ident) + LABELS[cand.kind], cand.chr_id
+            picked.append(mam(cx[r], cy[r], cc[r], cd[r], val, cj[r], msl, name, chr_id))
+        read_len = batch.reads[i] if native else len(batch.plans[i].read)
         gaps = []
         if picked:
             gaps.append(picked[0].c)
             for p, q in zip(picked[:-1], picked[1:]):
                 gaps.append(q.c - p.d - 1)
             gaps.append(read_len - picked[-1].d)
-        out.append((gaps, float(res["value"][i]), picked))
+        out.append((gaps, value[i], tuple(picked)))
     return out
 
 
