@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,7 @@ struct MamState {
     float ms[3] = {0, 0, 0}; // MAM build, chaining, chain gather
     std::vector<int64_t> h_instbase;
     std::vector<int32_t> h_nmam;
+    int64_t *pinned_total = nullptr; // total MAM slots of the batch, read back while the Myers passes still run
     DevBuf kind, estart, estop, pair, pairc, seqlen, seqid, candoff, readlen, fps, lps, cap, capoff, instbase, scantmp, flag,
         mx, my, mc, md, mmsl, mcand, mval, nmam, chainidx, chainlen, value, lenw, chainoff, cx, cy, cc, cd, cmsl, ccand, cj, cval;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -108,6 +110,9 @@ struct ultra_ctx {
     hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {};
     // lane i of a forked section: the three auxiliary streams, then the main stream itself
     hipStream_t lane(int i) const { i %= cfg.launch_lanes; return i < cfg.launch_lanes - 1 ? aux[i] : stream; }
+    // enqueued on `stream` by the Myers run right after the start pass has been launched: work of the caller that
+    // only needs the forward results rides under the remaining passes and shares their next host synchronisation
+    std::function<int()> mid_hook;
     ultra_cfg cfg;
     std::string err;
     hipDeviceProp_t prop;

@@ -326,6 +326,7 @@ void ultra_mam_free(ultra_ctx *ctx)
                       &m.ccand, &m.cj, &m.cval};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : m.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (m.pinned_total) { (void)hipHostFree(m.pinned_total); m.pinned_total = nullptr; }
 }
 
 extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
@@ -420,31 +421,39 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     m.ran = false;
     m.total_cap = m.total_chain = m.total_mam = 0;
     for (auto &v : m.ms) v = 0;
-    int rc = ultra_myers_run_impl(ctx, false);
-    if (rc != ULTRA_OK) return rc;
     const int32_t nc = m.n_cand, ni = m.n_inst;
+    MyersState &my = ctx->my;
+    hipStream_t s = ctx->stream;
+    if (!m.pinned_total) ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&m.pinned_total, 64, hipHostMallocDefault));
+    *m.pinned_total = 0;
+    m.h_instbase.clear();
+    // ---- slot layout: one slot per location of a candidate's pair (+1 for its contained-read pair).  It only needs
+    //      the forward pass, so it is enqueued from inside the Myers run (behind the start pass) and its total
+    //      comes back with that run's next host synchronisation. ----
+    ctx->mid_hook = [ctx, &m, &my, nc, ni, s]() -> int {
+        if (ni == 0) return ULTRA_OK;
+        if (nc > 0) {
+            hipLaunchKernelGGL(k_cand_cap, dim3((nc + 255) / 256), dim3(256), 0, s, m.pair.as<int32_t>(), m.pairc.as<int32_t>(),
+                               my.nloc.as<int32_t>(), m.cap.as<uint64_t>(), nc);
+            ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, m.cap.as<uint64_t>(), m.capoff.as<uint64_t>(), nc, m.scantmp));
+            hipLaunchKernelGGL(k_scan_close, dim3(1), dim3(64), 0, s, m.cap.as<uint64_t>(), m.capoff.as<uint64_t>(), (int64_t)nc);
+            hipLaunchKernelGGL(k_gather_i64, dim3((ni + 1 + 255) / 256), dim3(256), 0, s, m.capoff.as<int64_t>(), m.candoff.as<int64_t>(),
+                               m.instbase.as<int64_t>(), ni + 1);
+            ULTRA_HIP_CHECK(ctx, hipGetLastError());
+            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pinned_total, m.instbase.as<int64_t>() + ni, 8, hipMemcpyDeviceToHost, s));
+        } else {
+            ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.instbase.p, 0, ((size_t)ni + 1) * 8, s));
+            ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.capoff.p, 0, 8, s));
+        }
+        return ULTRA_OK;
+    };
+    int rc = ultra_myers_run_impl(ctx, false);
+    ctx->mid_hook = nullptr;
+    if (rc != ULTRA_OK) return rc;
     if (ni == 0) { m.ran = true; return ULTRA_OK; }
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    MyersState &my = ctx->my;
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[0], s));
-    // ---- slot layout: one slot per location of a candidate's pair (+1 for its contained-read pair) ----
-    m.h_instbase.assign((size_t)ni + 1, 0);
-    if (nc > 0) {
-        hipLaunchKernelGGL(k_cand_cap, dim3((nc + 255) / 256), dim3(256), 0, s, m.pair.as<int32_t>(), m.pairc.as<int32_t>(),
-                           my.nloc.as<int32_t>(), m.cap.as<uint64_t>(), nc);
-        ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, m.cap.as<uint64_t>(), m.capoff.as<uint64_t>(), nc, m.scantmp));
-        hipLaunchKernelGGL(k_scan_close, dim3(1), dim3(64), 0, s, m.cap.as<uint64_t>(), m.capoff.as<uint64_t>(), (int64_t)nc);
-        hipLaunchKernelGGL(k_gather_i64, dim3((ni + 1 + 255) / 256), dim3(256), 0, s, m.capoff.as<int64_t>(), m.candoff.as<int64_t>(),
-                           m.instbase.as<int64_t>(), ni + 1);
-        ULTRA_HIP_CHECK(ctx, hipGetLastError());
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_instbase.data(), m.instbase.p, ((size_t)ni + 1) * 8, hipMemcpyDeviceToHost, s));
-        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    } else {
-        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.instbase.p, 0, ((size_t)ni + 1) * 8, s));
-        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.capoff.p, 0, 8, s));
-    }
-    m.total_cap = m.h_instbase[(size_t)ni];
+    m.total_cap = *m.pinned_total;
     const size_t T = (size_t)std::max<int64_t>(m.total_cap, 1);
     ULTRA_HIP_CHECK(ctx, m.flag.ensure(T + 16));
     ULTRA_HIP_CHECK(ctx, m.mx.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.my.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.mc.ensure(T * 4));
@@ -574,6 +583,8 @@ extern "C" int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out)
             ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hk.data(), m.mcand.p, T * 4, hipMemcpyDeviceToHost, s));
             ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hv.data(), m.mval.p, T * 8, hipMemcpyDeviceToHost, s));
         }
+        m.h_instbase.resize((size_t)ni + 1);
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_instbase.data(), m.instbase.p, ((size_t)ni + 1) * 8, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         int64_t w = 0;
         for (int32_t i = 0; i < ni; i++) {

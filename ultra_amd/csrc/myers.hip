@@ -1178,7 +1178,15 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     st.ran = false;
     st.total_loc = st.total_hit = 0;
     for (auto &m : st.ms) m = 0;
-    if (n == 0) { st.ran = true; return ULTRA_OK; }
+    if (n == 0) {
+        if (ctx->mid_hook) {
+            const int hrc = ctx->mid_hook();
+            if (hrc != ULTRA_OK) return hrc;
+            ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        }
+        st.ran = true;
+        return ULTRA_OK;
+    }
     MyArgs a;
     memset(&a, 0, sizeof a);
     a.seq = st.seq.as<uint8_t>(); a.rseq = st.rseq.as<uint8_t>(); a.N = st.N; a.S = st.S;
@@ -1263,6 +1271,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
+    if (ctx->mid_hook) { const int hrc = ctx->mid_hook(); if (hrc != ULTRA_OK) return hrc; }
     // ---- pass 3: first-location traceback ----
     a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
     a.ops_off = want_ops ? st.opsoff.as<int64_t>() : nullptr;
