@@ -47,6 +47,10 @@ struct MyArgs {
     uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
     int64_t begin, end;
     int32_t *wflag; // per work item of a forward launch: some pair has more end columns than first-pass slots
+    // start pass: the work items of a launch follow from the location range of each size class, so they are
+    // computed from blockIdx (heaviest class first) instead of being listed by the host
+    struct { int32_t cls, first_block; int64_t b, e; } rr[4];
+    int32_t n_rr;
     int32_t nbb;    // lane-group traceback: 64-row blocks stored per column (the ones the path's band crosses); 0 = all
 };
 
@@ -517,7 +521,17 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
     extern __shared__ uint64_t lds[];
     if ((int32_t)blockIdx.x >= n) return;
     if (MODE == MODE_FWD_EXACT && !a.wflag[blockIdx.x]) return; // the forward launch over the same list left the flag
-    const WorkItem wi = list[blockIdx.x];
+    WorkItem wi;
+    if (list) wi = list[blockIdx.x];
+    else {
+        int r = 0;
+        while (r + 1 < a.n_rr && (int32_t)blockIdx.x >= a.rr[r + 1].first_block) r++;
+        wi.cls = a.rr[r].cls;
+        const int per = wi.cls < 4 ? 64 : wi.cls < 6 ? 32 : wi.cls < 8 ? 16 : wi.cls < 10 ? 8 : 1; // 64 / G of the class
+        wi.base = a.rr[r].b + (int64_t)((int32_t)blockIdx.x - a.rr[r].first_block) * per;
+        wi.end = a.rr[r].e;
+        wi.cost = 0;
+    }
     a.end = wi.end;
     if (BUCKET == 0) {
         if (wi.cls == 0) lane_item<1, MODE>(a, wi.base, lds, 0); else lane_item<2, MODE>(a, wi.base, lds, 0);
@@ -963,7 +977,12 @@ struct PassRange { int cls; int64_t b, e; const int32_t *t_len; };
 void build_work(const std::vector<PassRange> &ranges, std::vector<WorkItem> out[kBuckets])
 {
     for (int b = 0; b < kBuckets; b++) out[b].clear();
-    for (const PassRange &r : ranges) {
+    // Without target lengths (start pass) the cost of an item is its class's alone and grows with the class: walking the
+    // classes downwards IS heaviest first - no sort on the host while the GPU waits for this list.
+    bool by_class = true;
+    for (const PassRange &r : ranges) by_class = by_class && !r.t_len;
+    for (size_t ri = 0; ri < ranges.size(); ri++) {
+        const PassRange &r = by_class ? ranges[ranges.size() - 1 - ri] : ranges[ri];
         const int G = kClasses[r.cls].G, W = kClasses[r.cls].W;
         const int per = 64 / G;
         const int rows = 64 * G * W;
@@ -977,6 +996,7 @@ void build_work(const std::vector<PassRange> &ranges, std::vector<WorkItem> out[
             out[bucket_of(r.cls)].push_back(wi);
         }
     }
+    if (by_class) return;
     for (int b = 0; b < kBuckets; b++)
         std::stable_sort(out[b].begin(), out[b].end(), [](const WorkItem &x, const WorkItem &y) { return x.cost > y.cost; });
 }
@@ -1254,20 +1274,22 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     // ---- pass 2: start positions ----
     {
-        std::vector<PassRange> ranges;
-        for (auto &mc : st.classes)
-            if (mc.le > mc.lb) ranges.push_back(PassRange{class_of(64 * mc.G * mc.W), mc.lb, mc.le, nullptr});
-        build_work(ranges, st.h_work);
-        for (int b = 0; b < kBuckets; b++) {
-            MyersBucket &bk = st.buckets[b];
-            bk.n_rev = (int32_t)st.h_work[b].size();
-            if (bk.n_rev <= 0) continue;
-            ULTRA_HIP_CHECK(ctx, bk.rev_list.ensure(st.h_work[b].size() * sizeof(WorkItem)));
-            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(bk.rev_list.p, st.h_work[b].data(), st.h_work[b].size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
-        }
         ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
-        for (int b = kBuckets - 1; b >= 0; b--)
-            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_REV>(ctx, a, b, st.buckets[b].rev_list.as<WorkItem>(), st.buckets[b].n_rev));
+        for (int b = kBuckets - 1; b >= 0; b--) {
+            MyArgs ab = a;
+            ab.n_rr = 0;
+            int32_t blocks = 0;
+            for (auto mc = st.classes.rbegin(); mc != st.classes.rend(); ++mc) { // heaviest class of the bucket first
+                const int cls = class_of(64 * mc->G * mc->W);
+                if (bucket_of(cls) != b || mc->le <= mc->lb) continue;
+                const int per = 64 / mc->G;
+                ab.rr[ab.n_rr].cls = cls; ab.rr[ab.n_rr].first_block = blocks; ab.rr[ab.n_rr].b = mc->lb; ab.rr[ab.n_rr].e = mc->le;
+                ab.n_rr++;
+                blocks += (int32_t)((mc->le - mc->lb + per - 1) / per);
+            }
+            st.buckets[b].n_rev = blocks;
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_REV>(ctx, ab, b, nullptr, blocks));
+        }
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
