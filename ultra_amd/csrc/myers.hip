@@ -418,7 +418,7 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         int32_t score = it.m;
         int32_t best = 0x3fffffff, cnt = 0, lim = it.k, last = -1;
         int32_t *out = nullptr; int32_t out_cap = 0;
-        if (MODE == MODE_FWD) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
+        if (MODE == MODE_FWD && it.valid) { out = a.slots + (int64_t)it.pair * a.slot_cap; out_cap = a.slot_cap; }
         if (MODE == MODE_FWD_EXACT && it.valid) { out = a.loc_end + a.loc_off[it.pair]; out_cap = a.nloc[it.pair]; }
         ulonglong2 *tT = nullptr;
         if (MODE == MODE_NW) tT = a.tr + (slot0 + p) * a.region;
@@ -435,6 +435,61 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         const int nmax = wave_max_i32(n);
         const int steps = nmax + G - 1;
         uint32_t h_out = 0; // bit 0: +1 carry out of this lane's last word, bit 1: -1 carry
+        if (MODE != MODE_NW) {
+            // Forward / start passes.  Three things keep the per-step overhead down:
+            //  * every lane refills its 8 target bytes at the same steps (t % 8 == 0, from its own column t - g on:
+            //    an unaligned 8-byte load), so the refill is a uniform branch and the byte window shifts unconditionally;
+            //  * between the ramp-up and the shortest target of the wavefront every lane is inside its pair: those steps
+            //    run without range tests (lanes without a pair tag along on garbage with out_cap = 0, as in lane_item);
+            //  * only the last lane of a pair scores, by giving the others thresholds that never fire - no g == G-1 branch.
+            const bool lastlane = g == G - 1;
+            const int act_n = it.valid ? n : nmax;
+            const int nmin = -wave_max_i32(-act_n);
+            const uint8_t *tp = it.valid ? it.t : a.seq + 64; // 64 readable bytes lie in front of every target
+            int32_t limv = lastlane ? lim : (int32_t)0x80000000;
+            const int32_t revbest = lastlane ? it.best : (int32_t)0x80000000;
+            uint64_t tw = 0, twn = load8(tp - g);
+            auto step = [&](int t, auto tested) {
+                constexpr bool TESTED = decltype(tested)::value;
+                uint32_t h_in = G <= 16 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x111 /* row_shr:1 */, 0xf, 0xf, false)
+                                        : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                if (g == 0) h_in = top_hp;
+                uint32_t hp = h_in & 1u, hm = h_in >> 1;
+                const int col = t - g;
+                const int code = (int)(tw & 0xff);
+                tw >>= 8;
+                if (!TESTED || (col >= 0 && col < act_n)) {
+                    const uint64_t *pe = peq + (size_t)code * NB + g * W;
+#pragma unroll
+                    for (int w = 0; w < W; w++) {
+                        uint64_t ph0;
+                        word_step(Pv[w], Mv[w], pe[w], hp, hm, ph0);
+                    }
+                    h_out = hp | (hm << 1);
+                    score += (int32_t)hp - (int32_t)hm;
+                    if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
+                        if (score <= limv) {
+                            if (score < best) { best = score; cnt = 0; limv = score; }
+                            if (cnt < out_cap) out[cnt] = col;
+                            cnt++;
+                        }
+                    } else {
+                        if (score <= revbest) last = col;
+                    }
+                }
+            };
+            int t = 0;
+            auto refill = [&](int tt) {
+                tw = twn;
+                int pos = tt - g + 8;
+                pos = pos < act_n ? pos : act_n;
+                twn = load8(tp + pos);
+            };
+            const int t_fast0 = G - 1, t_fast1 = nmin > G - 1 ? nmin : G - 1;
+            for (; t < t_fast0 && t < steps; t++) { if ((t & 7) == 0) refill(t); step(t, std::true_type{}); }
+            for (; t < t_fast1; t++) { if ((t & 7) == 0) refill(t); step(t, std::false_type{}); }
+            for (; t < steps; t++) { if ((t & 7) == 0) refill(t); step(t, std::true_type{}); }
+        } else {
         uint64_t tw = 0;    // this lane's next target bytes (its column lags g steps behind lane 0)
         uint64_t twn = n > 0 ? load8(it.t) : 0; // the chunk after it, loaded eight columns ahead of its use
         for (int t = 0; t < steps; t++) {
@@ -453,28 +508,15 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                 for (int w = 0; w < W; w++) {
                     uint64_t ph0;
                     word_step(Pv[w], Mv[w], pe[w], hp, hm, ph0);
-                    if (MODE == MODE_NW) {
-                        ulonglong2 e; e.x = Pv[w]; e.y = ph0;
-                        int f = (col + lo_pad) >> 6;
-                        f = f < 0 ? 0 : f > NB - nbb ? NB - nbb : f;
-                        const int rel = g * W + w - f;
-                        if (rel >= 0 && rel < nbb) tT[(int64_t)col * nbb + rel] = e;
-                    }
+                    ulonglong2 e; e.x = Pv[w]; e.y = ph0;
+                    int f = (col + lo_pad) >> 6;
+                    f = f < 0 ? 0 : f > NB - nbb ? NB - nbb : f;
+                    const int rel = g * W + w - f;
+                    if (rel >= 0 && rel < nbb) tT[(int64_t)col * nbb + rel] = e;
                 }
                 h_out = hp | (hm << 1);
-                if (g == G - 1) {
-                    score += (int32_t)hp - (int32_t)hm;
-                    if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
-                        if (score <= lim) {
-                            if (score < best) { best = score; cnt = 0; lim = score; }
-                            if (cnt < out_cap) out[cnt] = col;
-                            cnt++;
-                        }
-                    } else if (MODE == MODE_REV) {
-                        if (score <= it.best) last = col;
-                    }
-                }
             }
+        }
         }
         if (MODE == MODE_FWD) {
             if (it.valid && g == G - 1) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
