@@ -89,7 +89,9 @@ struct MamState {
     float ms[3] = {0, 0, 0}; // MAM build, chaining, chain gather
     std::vector<int64_t> h_instbase;
     std::vector<int32_t> h_nmam;
-    int64_t *pinned_total = nullptr; // total MAM slots of the batch, read back while the Myers passes still run
+    int64_t *pinned_base = nullptr;  // pinned copy of instbase (first MAM slot of every instance, then the total), read
+    size_t pinned_cap = 0;           // back while the Myers passes still run; entries
+    std::vector<int32_t> h_slots;    // slots per instance = upper bound of its MAM count
     DevBuf kind, estart, estop, pair, pairc, seqlen, seqid, candoff, readlen, fps, lps, cap, capoff, instbase, scantmp, flag,
         mx, my, mc, md, mmsl, mcand, mval, nmam, chainidx, chainlen, value, lenw, chainoff, cx, cy, cc, cd, cmsl, ccand, cj, cval;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -326,7 +326,7 @@ void ultra_mam_free(ultra_ctx *ctx)
                       &m.ccand, &m.cj, &m.cval};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : m.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    if (m.pinned_total) { (void)hipHostFree(m.pinned_total); m.pinned_total = nullptr; }
+    if (m.pinned_base) { (void)hipHostFree(m.pinned_base); m.pinned_base = nullptr; m.pinned_cap = 0; }
 }
 
 extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
@@ -424,8 +424,12 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     const int32_t nc = m.n_cand, ni = m.n_inst;
     MyersState &my = ctx->my;
     hipStream_t s = ctx->stream;
-    if (!m.pinned_total) ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&m.pinned_total, 64, hipHostMallocDefault));
-    *m.pinned_total = 0;
+    if (m.pinned_cap < (size_t)ni + 1) {
+        if (m.pinned_base) { (void)hipHostFree(m.pinned_base); m.pinned_base = nullptr; m.pinned_cap = 0; }
+        ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&m.pinned_base, ((size_t)ni + 1 + 64) * 8, hipHostMallocDefault));
+        m.pinned_cap = (size_t)ni + 1 + 64;
+    }
+    memset(m.pinned_base, 0, ((size_t)ni + 1) * 8);
     m.h_instbase.clear();
     // ---- slot layout: one slot per location of a candidate's pair (+1 for its contained-read pair).  It only needs
     //      the forward pass, so it is enqueued from inside the Myers run (behind the start pass) and its total
@@ -440,7 +444,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
             hipLaunchKernelGGL(k_gather_i64, dim3((ni + 1 + 255) / 256), dim3(256), 0, s, m.capoff.as<int64_t>(), m.candoff.as<int64_t>(),
                                m.instbase.as<int64_t>(), ni + 1);
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
-            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pinned_total, m.instbase.as<int64_t>() + ni, 8, hipMemcpyDeviceToHost, s));
+            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pinned_base, m.instbase.p, ((size_t)ni + 1) * 8, hipMemcpyDeviceToHost, s));
         } else {
             ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.instbase.p, 0, ((size_t)ni + 1) * 8, s));
             ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.capoff.p, 0, 8, s));
@@ -453,7 +457,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     if (ni == 0) { m.ran = true; return ULTRA_OK; }
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[0], s));
-    m.total_cap = *m.pinned_total;
+    m.total_cap = m.pinned_base[ni];
     const size_t T = (size_t)std::max<int64_t>(m.total_cap, 1);
     ULTRA_HIP_CHECK(ctx, m.flag.ensure(T + 16));
     ULTRA_HIP_CHECK(ctx, m.mx.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.my.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.mc.ensure(T * 4));
@@ -483,14 +487,26 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[1], s));
-    m.h_nmam.resize((size_t)ni);
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
-    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    for (int32_t i = 0; i < ni; i++) m.total_mam += m.h_nmam[(size_t)i];
     // ---- chaining (solver switch of classify_read_with_mams.py:560-575) ----
+    // The host sorts the instances into launches by size.  An instance cannot hold more MAMs than it has slots, and
+    // the slot counts are on the host already: when none of them passes the solver switch every instance takes the
+    // quadratic solver whatever its exact size, and the launch needs no read-back of the MAM counts in between.
+    m.h_nmam.resize((size_t)ni);
+    m.h_slots.resize((size_t)ni);
+    bool exact_needed = false;
+    for (int32_t i = 0; i < ni; i++) {
+        const int64_t slots = m.pinned_base[i + 1] - m.pinned_base[i];
+        m.h_slots[(size_t)i] = (int32_t)slots;
+        if (slots > ctx->cfg.chain_switch_n) exact_needed = true;
+    }
+    if (exact_needed) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[2], s));
     int32_t *d_status = nullptr;
-    rc = ultra_chain_launch(ctx, ni, m.h_nmam.data(), m.instbase.as<int64_t>(), m.nmam.as<int32_t>(), a.mx, a.my, a.mc, a.md, a.mval,
+    rc = ultra_chain_launch(ctx, ni, exact_needed ? m.h_nmam.data() : m.h_slots.data(), m.instbase.as<int64_t>(), m.nmam.as<int32_t>(),
+                            a.mx, a.my, a.mc, a.md, a.mval,
                             0, -1, -1, m.chainidx.as<int32_t>(), m.chainlen.as<int32_t>(), m.value.as<double>(), &d_status);
     if (rc != ULTRA_OK) { (void)hipStreamSynchronize(s); return rc; }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[3], s));
@@ -511,7 +527,9 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     int32_t status = 0;
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_total, m.chainoff.as<int64_t>() + ni, 8, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+    if (!exact_needed) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    for (int32_t i = 0; i < ni; i++) m.total_mam += m.h_nmam[(size_t)i];
     if (status != 0)
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_run: an instance reached the reference's 'BUG' state in the n log n chainer");
     m.total_chain = h_total;
