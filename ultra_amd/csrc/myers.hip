@@ -234,6 +234,81 @@ __device__ __forceinline__ void traceback(const ulonglong2 *tr, int64_t stride, 
     n_ins = ins; n_ops = cnt;
 }
 
+// The same walk for the lane-group kernels, where G lanes share a pair and a single walker would fetch every tile
+// alone (measured: 2.7 - 4.5 ms of walk behind 1.1 ms of matrix fill for a 1742 x 1965 pair).  All lanes of the
+// wavefront call this: per round the walker's position goes to its group, up to 8 lanes of the group fetch a tile
+// of 16 entries each (8 G columns x the 2 blocks around the current row; every load in flight at once) into the
+// pair's LDS region, and the walker (lane g == 0) walks until it leaves the tile.  One wavefront per workgroup.
+template <int G>
+__device__ __forceinline__ void traceback_group(const ulonglong2 *tr, int nbb, int lo_pad, int pad, int rows, int L, bool valid,
+                                                const uint8_t *q, const uint8_t *t, uint8_t *ops, int ops_cap, int &n_ins, int &n_ops,
+                                                ulonglong2 *tile, int lane, int g)
+{
+    constexpr int GL = G < 8 ? G : 8; // lanes of a group that fetch
+    constexpr int E = 16 * GL;        // entries per tile
+    constexpr int TC = E / 2;         // columns per tile
+    const int nwords = rows >> 6;
+    auto at = [&](int ck, int w) {
+        int f = (ck + lo_pad) >> 6;
+        const int fmax = nwords - nbb;
+        f = f < 0 ? 0 : f > fmax ? fmax : f;
+        int rel = w - f;
+        rel = rel < 0 ? 0 : rel >= nbb ? nbb - 1 : rel; // blocks a staged column does not hold are never walked
+        return (int64_t)ck * nbb + rel;
+    };
+    int ip = rows - 1, c = L - 1, ins = 0, cnt = 0; // the walker's state (lane g == 0)
+    bool walking = valid && g == 0 && ip >= pad && c >= 0;
+    while (__any(walking)) {
+        const int src = lane - g;
+        const int wip = __shfl(ip, src, 64), wc = __shfl(c, src, 64);
+        const bool wwalking = __shfl((int)walking, src, 64) != 0;
+        int wlo = (wip - 32) >> 6;
+        wlo = wlo > nwords - 2 ? nwords - 2 : wlo;
+        wlo = wlo < 0 ? 0 : wlo;
+        const int w1 = wlo + 1 < nwords ? wlo + 1 : wlo;
+        if (wwalking && g < GL) {
+            ulonglong2 buf[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int e = g + k * GL;
+                const int ck = wc - (e >> 1) > 0 ? wc - (e >> 1) : 0;
+                buf[k] = tr[at(ck, (e & 1) ? w1 : wlo)];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) tile[g + k * GL] = buf[k];
+        }
+        __syncthreads();
+        if (walking) {
+            const int c_hi = c, win_lo = c - TC + 1;
+            while (ip >= pad && c >= 0 && c >= win_lo) {
+                const int w = ip >> 6;
+                if (w < wlo || w > wlo + 1) break;
+                const ulonglong2 e = tile[(c_hi - c) * 2 + (w - wlo)];
+                const uint64_t bit = ((uint64_t)1) << (ip & 63);
+                int code;
+                if (e.x & bit) { code = 1; ins++; ip--; }
+                else if (e.y & bit) { code = 2; c--; }
+                else { code = (ops && q[ip - pad] != t[c]) ? 3 : 0; ip--; c--; }
+                if (ops && cnt < ops_cap) ops[cnt] = (uint8_t)code;
+                cnt++;
+            }
+            walking = ip >= pad && c >= 0;
+        }
+        __syncthreads(); // the tile is overwritten in the next round
+    }
+    if (valid && g == 0) {
+        if (ip >= pad) { // left boundary reached: the remaining query bases are insertions
+            const int r = ip - pad + 1;
+            if (ops) for (int u = 0; u < r; u++) if (cnt + u < ops_cap) ops[cnt + u] = 1;
+            ins += r; cnt += r;
+        } else if (c >= 0) { // query used up: the remaining target bases are deletions
+            if (ops) for (int u = 0; u <= c; u++) if (cnt + u < ops_cap) ops[cnt + u] = 2;
+            cnt += c + 1;
+        }
+        n_ins = ins; n_ops = cnt;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // lane-per-pair kernel: W words per lane in registers
 // ------------------------------------------------------------------------------------------------
@@ -526,14 +601,17 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
             if (it.valid && g == G - 1) a.loc_start[base + p] = a.loc_end[base + p] - last;
         } else if (MODE == MODE_NW) {
             __threadfence();
-            if (it.valid && g == 0) {
+            {
                 uint8_t *ops = nullptr; int ops_cap = 0;
-                if (a.ops) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
-                int ins, nops;
-                traceback(tT, 1, (int64_t)nbb, pad, ROWS, it.n, it.q, it.t, ops, ops_cap, ins, nops,
-                          (ulonglong2 *)(lds_wave + (size_t)S * NB * P) + lane, nbb, lo_pad);
-                a.first_ins[it.pair] = ins;
-                if (a.n_ops) a.n_ops[it.pair] = nops;
+                if (a.ops && it.valid) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
+                int ins = 0, nops = 0;
+                constexpr int TILE = 16 * (G < 8 ? G : 8); // entries of a pair's tile: P * TILE <= 1024 = the staging area
+                traceback_group<G>(tT, nbb, lo_pad, pad, ROWS, it.n, it.valid, it.q, it.t, ops, ops_cap, ins, nops,
+                                   (ulonglong2 *)(lds_wave + (size_t)S * NB * P) + (size_t)p * TILE, lane, g);
+                if (it.valid && g == 0) {
+                    a.first_ins[it.pair] = ins;
+                    if (a.n_ops) a.n_ops[it.pair] = nops;
+                }
             }
             __threadfence();
         }
