@@ -184,3 +184,44 @@ def test_native_plan_gives_the_same_results(ctx, preset):
         assert g[0] == w_[0]
         assert struct.pack("d", float(g[1])) == struct.pack("d", float(w_[1]))
         assert tuple(tuple(m) for m in g[2]) == tuple(tuple(m) for m in w_[2])
+
+
+def test_launch_lanes_and_empty_batches(ctx):
+    """Results do not depend on how many streams the launches of a pass are dealt over (1, 4 or 8 lanes), and batches
+    whose candidates yield no Myers pair at all (every segment narrower than 5 bp) or no candidate at all come back as
+    the reference's empty result ([], -1, ()) - the slot layout that rides inside the Myers run must cope with both."""
+    from array import array
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import lib, synth
+    from ultra_amd.synth import Mem, key_of
+    w = synth.make_world(seed=23, n_genes=30)
+    idx = w.index()
+    insts = synth.make_instances(w, 120, seed=7, preset="ont_drna", flank_start_prob=0.3, flank_end_prob=0.3)
+    pairs = [(sol, read) for read, sol, _ in insts]
+    want = stage.main_batch(pairs, *idx, min_acc=0.6, ctx=ctx)
+    for lanes in (1, 4, 8):
+        c = lib.Context(0, cfg={"launch_lanes": lanes})
+        try:
+            got = stage.main_batch(pairs, *idx, min_acc=0.6, ctx=c)
+        finally:
+            c.close()
+        assert all(_same(a, b) for a, b in zip(want, got)), lanes
+    # a world whose only segments are 3-4 bp wide: candidates exist, pairs do not
+    seg = {key_of(1, 100, 104): "ACGT", key_of(1, 300, 303): "TTG"}
+    s2g = {k: {"g"} for k in seg}
+    p2s = {key_of(1, 90, 320): array('L', [1, 100, 104, 1, 300, 303])}
+    g2s = {"g": array('L', [1, 100, 104, 1, 300, 303])}
+    tiny = (seg, {}, p2s, s2g, g2s)
+    read = "ACGTTTGACGTACGTACGATCGATCGTAGCTAGCTAGCATCGATCGAT"
+    sols = [[Mem(100, 103, 0, 3, 4, 0, "1^90^320")], [Mem(300, 302, 10, 12, 3, 0, "1^90^320")], []]
+    got = stage.main_batch([(s, read) for s in sols], *tiny, min_acc=0.6, ctx=ctx)
+    for s, g in zip(sols, got):
+        assert _same(classify_port.classify(s, *tiny, read, None, 0.6), g)
+        assert g == ([], -1, ())
+    # mixed: the same empty instances between real ones of another world cannot be batched (one index per batch),
+    # but an instance with an empty NAM chain inside a real batch can
+    mixed = pairs[:5] + [([], insts[0][0])] + pairs[5:10]
+    got = stage.main_batch(mixed, *idx, min_acc=0.6, ctx=ctx)
+    assert got[5] == ([], -1, ())
+    assert all(_same(a, b) for a, b in zip(want[:5] + want[5:10], got[:5] + got[6:]))
