@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=131072, help="reads (instances) per step and per GPU")
+    ap.add_argument("--reads", type=int, default=262144, help="reads (instances) per step and per GPU")
     ap.add_argument("--preset", default="ont_cdna", choices=["ont_cdna", "isoseq", "ont_drna"])
     ap.add_argument("--genes", type=int, default=1500)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
