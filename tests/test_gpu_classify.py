@@ -225,3 +225,49 @@ def test_launch_lanes_and_empty_batches(ctx):
     got = stage.main_batch(mixed, *idx, min_acc=0.6, ctx=ctx)
     assert got[5] == ([], -1, ())
     assert all(_same(a, b) for a, b in zip(want[:5] + want[5:10], got[:5] + got[6:]))
+
+
+def test_stage_properties_at_bench_scale(ctx):
+    """Size-independent properties of the whole stage at a bench-like size (32 768 instances, planned natively, one
+    device batch): chains are colinear (j, y and read intervals ascend as the solver allows), every MAM lies inside
+    its read, the non-covered regions add up with the covered ones to the read length, values are finite and
+    positive, re-running the staged batch reproduces the fetch bit for bit, and a seeded sample equals the oracle."""
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import index as native
+    from ultra_amd import synth
+    w = synth.make_world(seed=51, n_genes=400, n_chr=4)
+    idx = w.index()
+    insts = synth.make_instances(w, 32768, seed=13, preset="ont_cdna")
+    ix = native.NativeIndex(*idx)
+    try:
+        plan = ix.plan([(sol, read) for read, sol, _ in insts])
+        stage.stage_batch(ctx, plan)
+        stage.run_staged(ctx, 0.6)
+        res1 = ctx.mam_fetch()
+        stage.run_staged(ctx, 0.6)
+        res2 = ctx.mam_fetch()
+        for k in res1:
+            assert np.array_equal(np.asarray(res1[k]), np.asarray(res2[k])), k
+        out = stage.results_to_python(plan, res1)
+    finally:
+        ix.close()
+    assert len(out) == len(insts)
+    n_nonempty = 0
+    for (read, sol, _), (gaps, value, mams) in zip(insts, out):
+        if not mams:
+            assert (gaps, value) == ([], -1)
+            continue
+        n_nonempty += 1
+        assert np.isfinite(value) and value > 0
+        js = [m.j for m in mams]
+        assert js == sorted(set(js))
+        assert all(m.y >= p.y for p, m in zip(mams[:-1], mams[1:]))          # sorted by y before chaining (:553)
+        assert all(0 <= m.c <= m.d < len(read) for m in mams)
+        covered = sum(m.d - m.c + 1 for m in mams)
+        # gaps = [c0, c1 - d0 - 1, ..., len - d_last] (:579-592; the last term has no -1, overlaps make terms negative)
+        assert sum(gaps) + covered == len(read) + 1
+    assert n_nonempty > 0.9 * len(insts)
+    for i in range(0, len(insts), 997):
+        read, sol, _ = insts[i]
+        assert _same(classify_port.classify(sol, *idx, read, None, 0.6), out[i])
