@@ -284,7 +284,6 @@ def results_to_python(batch, res):
     cval, cmsl, ccand, cj = res["chain_val"].tolist(), res["chain_msl"].tolist(), res["chain_cand"].tolist(), res["chain_j"].tolist()
     if native:
         kinds, chrs = batch.packed["cand_kind"].tolist(), batch.cand_chr.tolist()
-        names = {}
     for i in range(batch.n_inst):
         if n_mam[i] == 0:
             out.append(([], -1, tuple()))
@@ -294,10 +293,7 @@ def results_to_python(batch, res):
             ci, msl = ccand[r], cmsl[r]
             val = int(cval[r]) if msl == 0 else cval[r]  # 5-8 bp exact segment: the reference stores the int len(exon_seq) (:357-367)
             if native:
-                name = names.get(ci)
-                if name is None:
-                    name = names[ci] = batch.mam_id(ci, LABELS[kinds[ci]])
-                chr_id = chrs[ci]
+                name, chr_id = batch.mam_id(ci, LABELS[kinds[ci]]), chrs[ci]
             else:
                 cand = batch.plans[i].cands[ci - coff[i]]
                 name, chr_id = str(cand.ident) + LABELS[cand.kind], cand.chr_id

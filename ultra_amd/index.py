@@ -33,6 +33,7 @@ class NativePlan(object):
 
     def __init__(self, so, handle, reads, n_inst):
         self._so, self.handle, self.reads, self.n_inst = so, handle, reads, n_inst
+        self._cols, self._names = None, {}
         inp = so.ultra_plan_input(handle).contents
         self.n_pairs, self.n_cand = int(inp.n_pairs), int(inp.n_cand)
         chr_p, ident_p, cells = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.c_double()
@@ -62,11 +63,19 @@ class NativePlan(object):
 
     def mam_id(self, ci, label):
         """The reference's mam_id of candidate ci: str(segm_id) + label (classify_read_with_mams.py:445, :456)."""
-        kind = int(self.packed["cand_kind"][ci])
-        a, b = int(self.packed["cand_e_start"][ci]), int(self.packed["cand_e_stop"][ci])
-        if kind in (1, 4, 5):
-            return "flank_{0}_{1}".format(a, b) + label
-        return str(array('L', [int(self.cand_ident_chr[ci]), a, b]).tobytes()) + label
+        if self._cols is None:  # plain lists: numpy scalar indexing costs more than the name itself
+            self._cols = (self.packed["cand_kind"].tolist(), self.packed["cand_e_start"].tolist(),
+                          self.packed["cand_e_stop"].tolist(), self.cand_ident_chr.tolist())
+        kinds, starts, stops, chrs = self._cols
+        key = (kinds[ci], chrs[ci], starts[ci], stops[ci])
+        name = self._names.get(key)
+        if name is None:  # segments recur across the reads of a batch
+            if key[0] in (1, 4, 5):
+                name = "flank_{0}_{1}".format(key[2], key[3]) + label
+            else:
+                name = str(array('L', [key[1], key[2], key[3]]).tobytes()) + label
+            self._names[key] = name
+        return name
 
     def close(self):
         if self.handle is not None:
