@@ -110,7 +110,7 @@ struct ultra_ctx {
     // that short launches overlap (fork = aux streams wait for `stream`, join = `stream` waits for them)
     hipStream_t aux[kAuxStreams] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {};
-    // lane i of a forked section: the three auxiliary streams, then the main stream itself
+    // lane i of a forked section: the auxiliary streams in use, then the main stream itself
     hipStream_t lane(int i) const { i %= cfg.launch_lanes; return i < cfg.launch_lanes - 1 ? aux[i] : stream; }
     // enqueued on `stream` by the Myers run right after the start pass has been launched: work of the caller that
     // only needs the forward results rides under the remaining passes and shares their next host synchronisation

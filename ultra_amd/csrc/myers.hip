@@ -1511,7 +1511,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
         }
     }
-    // 3b: full-height kernels for what is left (distance > 254, or edit scripts wanted, or banding off).
+    // 3b: full-height kernels for what is left (distance > 374, or edit scripts wanted, or banding off).
     //     Their own scratch buffer, split between the classes that have work; the launches overlap with
     //     each other and with the banded ones (these are bound by their critical path, not by the ALUs).
     const bool need_full = !use_band || h_band[kBandFallback] > 0;
