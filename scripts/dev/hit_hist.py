@@ -1,0 +1,30 @@
+"""Development aid: distribution of hits over the traceback classes for the bench workload (run on the GPU box)."""
+import os
+os.environ["GPU_MAX_HW_QUEUES"] = "8"
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch  # noqa: F401
+from ultra_amd import synth, lib, index as native
+from ultra_amd import classify_read_with_mams as stage
+
+w = synth.make_world(seed=20241008, n_genes=1500, n_chr=8)
+insts = synth.make_instances(w, 32768, seed=1000, preset="ont_cdna")
+ix = native.NativeIndex(*w.index())
+plan = ix.plan([(sol, read) for read, sol, _ in insts])
+ctx = lib.Context(0)
+stage.stage_batch(ctx, plan)
+stage.run_staged(ctx, 0.6)
+r = ctx.myers_fetch()
+ed = np.asarray(r["ed"])
+hit = ed >= 0
+off = np.asarray(r["loc_off"])
+L = np.zeros(len(ed), np.int64)
+ls, le = np.asarray(r["loc_start"]), np.asarray(r["loc_end"])
+first = off[:-1][hit]
+L[hit] = le[first] - ls[first] + 1
+print("pairs", len(ed), "hits", int(hit.sum()))
+for lo, hi in [(0, 22), (23, 54), (55, 118), (119, 246), (247, 374), (375, 10**9)]:
+    m = hit & (ed >= lo) & (ed <= hi)
+    if m.any():
+        print("ed %d..%d: hits %d  sum L %d  mean L %.0f  max L %d" % (lo, hi, m.sum(), L[m].sum(), L[m].mean(), L[m].max()))

@@ -135,7 +135,7 @@ def test_banded_traceback_wide_alphabet(ctx):
 def test_banded_traceback_skewed_paths(ctx, mix):
     """The band is shifted per pair towards the diagonals its path can reach (end diagonal m - L): deletion-only,
     insertion-only and long contiguous gaps put the path far from the main diagonal, and the rates make the
-    distances straddle every band-class limit (54, 118, 246, 374)."""
+    distances straddle every band-class limit (22, 54, 118, 246, 374)."""
     rng = np.random.RandomState(13 + int(mix[0] * 10) + int(mix[2] * 100))
     for qr, tr, n, rates, block in [((9, 260), (100, 900), 1200, (0.05, 0.2, 0.3, 0.38), 0),
                                     ((100, 400), (300, 1000), 500, (0.1, 0.2, 0.3), 60),
@@ -143,3 +143,5 @@ def test_banded_traceback_skewed_paths(ctx, mix):
                                     ((600, 1500), (900, 2400), 80, (0.08, 0.17, 0.33), 200)]:
         got = _check(ctx, helpers.make_pairs(rng, n, qr, tr, kmode="ref", planted=0.9, rates=rates, mix=mix, block=block))
         assert (got["ed"] > 54).any()
+        if block == 0:
+            assert ((got["ed"] >= 0) & (got["ed"] <= 22)).any() and ((got["ed"] > 22) & (got["ed"] <= 54)).any()

@@ -27,11 +27,14 @@
 namespace {
 
 enum { MODE_FWD = 0, MODE_FWD_EXACT = 1, MODE_REV = 2, MODE_NW = 3 };
-enum { kBandClasses = 4, kBandFallback = 4 }; // banded traceback: WB = 1, 2, 4, 6 words; class 4 = not banded
+enum { kBandClasses = 5, kBandFallback = 5 }; // banded traceback: 32 rows, then WB = 1, 2, 4, 6 words; class 5 = not banded
 // A lane-per-hit band kernel is bound by its longest lane (words x columns, twice): 6 words cover all but a
 // handful of hits per batch, and those few are quicker through the lane-group full-height kernels than through
-// an 8-word band.
-__host__ __device__ constexpr int band_words(int c) { return c < 2 ? c + 1 : c == 2 ? 4 : 6; }
+// an 8-word band.  Most hits need far less than one word (distance <= 22): they get a 32-row band of their own,
+// half the arithmetic, checkpoint bytes and LDS of the 1-word band (myers_band32).
+__host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : 6; } // classes 1..4
+__host__ __device__ constexpr int band_rows(int c) { return c == 0 ? 32 : 64 * band_words(c); }
+__host__ __device__ constexpr int band_chunk(int c) { return c <= 1 ? 16 : 8; } // columns per checkpoint
 
 struct MyArgs {
     const uint8_t *seq, *rseq;
@@ -886,6 +889,138 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
     }
 }
 
+// The same kernel on a 32-row window (bit b <-> query row c - 15 + off + b), for hits with ed <= 22: every
+// quantity is one 32-bit register, a checkpoint is 2 + NP dwords, a stored column 8 bytes per lane, so twice as
+// many wavefronts fit beside each other (the traceback launches are bound by latency, not by arithmetic).
+template <int NP>
+__global__ void __launch_bounds__(64) myers_band32(MyArgs a, const int32_t *items, int64_t n_items)
+{
+    constexpr int TOP = 15;
+    constexpr int K = band_chunk(0);
+    constexpr int CPW = 2 + NP; // dwords per checkpoint and lane
+    const int lane = threadIdx.x;
+    const int64_t gwave = blockIdx.x, nwaves = gridDim.x;
+    uint32_t *CP = (uint32_t *)((uint64_t *)a.tr + gwave * a.region) + lane; // checkpoint (chunk h, dword f) at CP[(h * CPW + f) * 64]
+    extern __shared__ uint2 band32_lds[];
+    uint2 *col = band32_lds + lane; // column k of the chunk at col[k * 64]
+    for (int64_t base = gwave * 64; base < n_items; base += nwaves * 64) {
+        const bool valid = base + lane < n_items;
+        int p = 0, m = 0, L = 0, ed = 0;
+        const uint8_t *q = a.seq, *t = a.seq;
+        if (valid) {
+            p = items[base + lane];
+            m = a.q_len[p];
+            ed = a.ed[p];
+            const int64_t lo = a.loc_off[p];
+            const int s0 = a.loc_start[lo];
+            L = a.loc_end[lo] - s0 + 1;
+            q = a.seq + a.q_off[p];
+            t = a.seq + a.t_off[p] + s0;
+        }
+        const int delta = m - L;
+        const int hh = (ed - (delta < 0 ? -delta : delta)) >> 1;
+        const int off = ((delta < 0 ? delta : 0) - hh - 1 + TOP) & ~7; // see myers_band
+        uint32_t PL[NP], VP, VN = 0;
+        uint64_t qw = 0, tw = 0, qwn = 0, twn = 0;
+        int pref_c = -0x40000000;
+        auto qblock = [&](int r) { return (r >= 0 && r < m) ? load8(q + r) : (uint64_t)0; };
+        auto prefetch = [&](int cn) {
+            pref_c = cn;
+#ifdef BAND32_DIAG
+            twn = 0x0102030001020300ull + cn; qwn = 0x0302010003020100ull + cn;
+#else
+            twn = (cn >= 0 && cn < L) ? load8(t + cn) : 0;
+            qwn = qblock(TOP + 1 + off + cn);
+#endif
+        };
+        auto push_row = [&](uint32_t code1) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) PL[k] = __builtin_amdgcn_alignbit(code1 >> k, PL[k], 1);
+        };
+        auto column = [&](int c, int k, bool store, int next_c) {
+            if ((c & 7) == 0) {
+                if (pref_c != c) prefetch(c);
+                tw = twn; qw = qwn;
+                prefetch(next_c);
+            }
+            const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
+            tw >>= 8;
+            uint32_t Eq = PL[0] ^ (((tc1 >> 0) & 1u) - 1u);
+#pragma unroll
+            for (int kk = 1; kk < NP; kk++) Eq = bop3<0x60>(Eq, PL[kk], ((tc1 >> kk) & 1u) - 1u);
+            const uint32_t sum = (Eq & VP) + VP;
+            const uint32_t D0 = bop3<0xBE>(sum, VP, Eq) | VN;
+            const uint32_t HP = bop3<0xF1>(VN, D0, VP);
+            const uint32_t HN = D0 & VP;
+            const uint32_t X = D0 >> 1;
+            VN = X & HP;
+            VP = bop3<0xF1>(HN, X, HP);
+            if (store) col[k * 64] = make_uint2(VP, HP >> 1);
+            const int r = TOP + 1 + off + c;
+            push_row((r >= 0 && r < m) ? (uint32_t)(qw & 0xff) + 1u : 0u);
+            qw >>= 8;
+        };
+#pragma unroll
+        for (int k = 0; k < NP; k++) PL[k] = 0;
+        {
+            const int r_end = TOP + 1 + off, r0 = off - TOP - 1;
+            int ri = r0 < 0 ? (r_end < 0 ? r_end : 0) : r0;
+            uint64_t cur = 0, nxt = qblock(ri);
+            while (ri < r_end) {
+                if ((ri & 7) == 0) { cur = nxt; nxt = qblock(ri + 8); }
+                push_row((ri >= 0 && ri < m) ? (uint32_t)(cur & 0xff) + 1u : 0u);
+                cur >>= 8;
+                ri++;
+            }
+        }
+        {
+            const int z = TOP + 1 - off; // bit b <-> row -1 - TOP + off + b >= 0
+            VP = z <= 0 ? ~0u : z >= 32 ? 0u : (~0u) << z;
+        }
+        const int Lmax = wave_max_i32(L);
+        const int nchunk = (Lmax + K - 1) / K;
+        for (int h = 0; h < nchunk; h++) {
+            if (h * K < L) {
+                uint32_t *cp = CP + (int64_t)h * CPW * 64;
+                cp[0] = VP; cp[64] = VN;
+#pragma unroll
+                for (int k = 0; k < NP; k++) cp[(2 + k) * 64] = PL[k];
+            }
+            if (h + 1 < nchunk)
+                for (int k = 0; k < K; k++) column(h * K + k, k, false, h * K + k + 8);
+        }
+        int r = m - 1, c = L - 1, ins = 0;
+        bool walking = valid;
+        for (int h = nchunk - 1; h >= 0; h--) {
+            const int c0 = h * K;
+            const bool act = walking && c0 < L;
+            if (!__any(act)) continue;
+            if (act) {
+                const uint32_t *cp = CP + (int64_t)h * CPW * 64;
+                VP = cp[0]; VN = cp[64];
+#pragma unroll
+                for (int k = 0; k < NP; k++) PL[k] = cp[(2 + k) * 64];
+            }
+            for (int k = 0; k < K; k++) column(c0 + k, k, true, k + 8 < K ? c0 + k + 8 : c0 - K);
+            if (act) {
+                while (r >= 0 && c >= c0) {
+                    const int b = r - c + TOP - off;
+                    const uint2 e = col[(c - c0) * 64];
+                    const uint32_t bit = 1u << (b & 31);
+                    if (e.x & bit) { ins++; r--; }
+                    else if (e.y & bit) c--;
+                    else { r--; c--; }
+                }
+                if (r < 0) walking = false;
+            }
+        }
+        if (valid) {
+            if (r >= 0) ins += r + 1;
+            a.first_ins[p] = ins;
+        }
+    }
+}
+
 // Sort key of every hit: band class by its distance (band rows needed: 2*ed + 3), then the length
 // of its first location, longest first - the lanes of a wavefront then run equally long.  Hits beyond
 // every band class are keyed by the size class of their query instead: each full-height kernel then
@@ -909,7 +1044,7 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
     const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
     // ed + 1 diagonals, one spare on either side, up to 7 lost to the window's 8-row alignment: ed <= 64 WB - 10
     uint32_t c = 0;
-    while (c < kBandFallback && ed > 64 * band_words((int)c) - 10) c++;
+    while (c < kBandFallback && ed > band_rows((int)c) - 10) c++;
     if (c < kBandFallback) keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
     else {
         const uint32_t sc = size_class_of(a.q_len[p]);
@@ -917,7 +1052,7 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
         atomicMax(&edmax[sc], ed);
     }
 }
-// info[g] = first sorted position of group g (band classes 0..3, then the 14 size classes of the
+// info[g] = first sorted position of group g (the band classes, then the 14 size classes of the
 // rest, then the end); info[kBandBounds + c] = longest first location of band class c
 __global__ void k_band_bounds(const uint32_t *keys, int64_t n, int32_t *info)
 {
@@ -1428,6 +1563,10 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     for (auto &v : full_first) v = 0;
     for (auto &v : full_edmax) v = 0;
     const int32_t *d_items_sorted = nullptr;
+    // The banded launches are prepared first (the full-height ones need their sort) but enqueued last: the few,
+    // long wavefronts of the full-height kernels and of the wide bands set the length of the phase, and launched
+    // behind the thousands of narrow-band wavefronts they would wait for LDS before they even start.
+    std::function<int()> launch_bands = [] { return (int)ULTRA_OK; };
     if (use_band) {
         // 3a: banded kernels for every hit whose distance fits a band of at most 512 rows
         const size_t NH = (size_t)n_hits;
@@ -1465,14 +1604,13 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         int64_t units[kBandClasses], region[kBandClasses];
         size_t total_words = 0;
         for (int c = 0; c < kBandClasses; c++) {
-            const int WB = band_words(c);
-            const int K = WB <= 1 ? 16 : 8;
+            const int K = band_chunk(c);
             units[c] = region[c] = 0;
             if (h_band[c] <= 0) continue;
             const int64_t chunks = ((int64_t)h_band[kBandClasses + 1 + c] + K - 1) / K;
-            region[c] = chunks * (2 + np) * WB * 64;
+            region[c] = chunks * (2 + np) * band_rows(c); // 64-bit words per wavefront: 64 lanes x rows / 64 words each
             const int64_t waves = ((int64_t)h_band[c] + 63) / 64;
-            int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * 10);
+            int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * (c == 0 ? 20 : 10));
             u = std::min<int64_t>(u, std::max<int64_t>(1, (int64_t)((budget / kBandClasses) / (size_t)(region[c] * 8))));
             units[c] = u;
             total_words += (size_t)region[c] * (size_t)u;
@@ -1480,6 +1618,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ULTRA_HIP_CHECK(ctx, st.trace.ensure(total_words * 8 + 64));
         ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
         forked = true;
+        std::vector<int64_t> v_units(units, units + kBandClasses), v_region(region, region + kBandClasses);
+        std::vector<int32_t> v_first(band_first, band_first + kBandClasses + 1), v_count(h_band, h_band + kBandClasses);
+        launch_bands = [=, &st]() -> int {
+        const int64_t *units = v_units.data(), *region = v_region.data();
+        const int32_t *band_first = v_first.data(), *h_band = v_count.data();
         size_t at = 0;
         for (int c = kBandClasses - 1; c >= 0; c--) {
             if (h_band[c] <= 0) continue;
@@ -1492,8 +1635,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             hipStream_t cs = ctx->lane(c);
             const int64_t ni = h_band[c];
             const int WB = band_words(c);
-            const size_t band_lds = (size_t)(WB <= 1 ? 16 : 8) * WB * 64 * sizeof(ulonglong2); // K columns x WB words per lane
-            if (np == 3) {
+            const size_t band_lds = (size_t)band_chunk(c) * band_rows(c) * 16; // K columns x {Pv, Ph} of the window per lane
+            if (c == 0) {
+                if (np == 3) hipLaunchKernelGGL((myers_band32<3>), grid, block, band_lds, cs, b, items, ni);
+                else hipLaunchKernelGGL((myers_band32<5>), grid, block, band_lds, cs, b, items, ni);
+            } else if (np == 3) {
                 switch (WB) {
                 case 1: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, band_lds, cs, b, items, ni); break;
                 case 2: hipLaunchKernelGGL((myers_band<2, 3>), grid, block, band_lds, cs, b, items, ni); break;
@@ -1510,6 +1656,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             }
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
         }
+        return ULTRA_OK;
+        };
     }
     // 3b: full-height kernels for what is left (distance > 374, or edit scripts wanted, or banding off).
     //     Their own scratch buffer, split between the classes that have work; the launches overlap with
@@ -1568,8 +1716,17 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             b.region = it->region; b.Lmax = (int32_t)it->Lmax; b.nbb = it->nbb;
             b.begin = it->begin; b.end = it->end;
             b.nw_items = use_band ? d_items_sorted : nullptr;
-            ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->lane(kBandClasses + q), it->cls, b, it->items, it->max_par));
+            // a lane of their own while there are lanes; beyond that beside the 1-word band and up, never behind the
+            // 32-row band's launch (lane 0, the longest of the phase)
+            int li = kBandClasses + q;
+            const int lanes = ctx->cfg.launch_lanes;
+            if (li >= lanes && lanes > 1) li = 1 + (li - lanes) % (lanes - 1);
+            ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->lane(li), it->cls, b, it->items, it->max_par));
         }
+    }
+    {
+        const int rc = launch_bands();
+        if (rc != ULTRA_OK) return rc;
     }
     if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[3], s));

@@ -287,12 +287,14 @@ class Context(object):
         inp.n_cand = len(keep["cand_kind"])
         inp.n_inst = len(keep["inst_read_len"])
         self._mam_n_inst = inp.n_inst
+        self._staged_n = inp.n_pairs  # myers_fetch works on the stage's pairs too
         self._check(self.lib.ultra_mam_stage(self._h, C.byref(inp)))
 
     def mam_stage_plan(self, plan):
         """plan: ultra_amd.index.NativePlan - its ultra_mam_input goes to the device as it is (no numpy round trip)."""
         inp = self.lib.ultra_plan_input(plan.handle)
         self._mam_n_inst = int(inp.contents.n_inst)
+        self._staged_n = int(inp.contents.n_pairs)
         self._check(self.lib.ultra_mam_stage(self._h, inp))
 
     def mam_run(self, min_acc):
