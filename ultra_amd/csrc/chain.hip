@@ -70,6 +70,7 @@ struct ChainArgs {
     uint8_t *work;       // global scratch (n log n)
     const int64_t *work_off;
     int32_t *status;
+    int32_t skip_tiny;   // chain_quadratic: instances of at most kTiny MAMs were done by chain_tiny
     // NAM (seed) chaining, SURVEY.md section 8 row f1: integer read-coverage objective of
     // colinear_solver.py:85-272; the whole DP vectors are the output (every co-optimal chain is wanted)
     int32_t nam;               // 0 = MAM objective, 1 = NAM objective
@@ -77,6 +78,8 @@ struct ChainArgs {
     int64_t *C_out;            // [total + n_inst]: instance i at off[i] + i, n + 1 entries, C[0] = 0
     int32_t *trace_out;        // same layout, trace[0] = -1
 };
+
+constexpr int kTiny = 16; // largest instance of the lane-per-instance kernel (chain_tiny)
 
 // ---- quadratic ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
@@ -90,6 +93,7 @@ __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
     const int n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
     const int cap = a.cap;
     const bool nam = a.nam != 0;
+    if (a.skip_tiny && n <= kTiny) return; // chain_tiny has done it
     uint8_t *base = lds_raw + (size_t)wave * cap * (nam ? 24 : 20);
     double *sC = (double *)base;
     int32_t *sc = (int32_t *)(base + (size_t)cap * 8);
@@ -171,6 +175,74 @@ __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
         a.len[inst] = len;
         a.value[inst] = B.v;
     }
+}
+
+// ---- quadratic, tiny instances -------------------------------------------------------------------
+// Most (read, location) instances hold a handful of MAMs: a wavefront per instance would idle 60 of its
+// lanes and spend its time in two wave-wide reductions per MAM.  Instances of at most kTiny MAMs get one
+// LANE each: the same recurrence evaluated sequentially (j' ascending through better_hi, i.e. the same
+// maxima and the same tie rules), the DP vectors in lane-private LDS columns.  The host sorts the list by
+// size, so the lanes of a wavefront run equally long.
+__global__ void __launch_bounds__(64) chain_tiny(ChainArgs a)
+{
+    __shared__ double sC[kTiny * 64], sV[kTiny * 64];
+    __shared__ int32_t sc[kTiny * 64], sd[kTiny * 64], sp[kTiny * 64];
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    int inst = 0, n = 0;
+    int64_t o = 0;
+    if (slot < a.nlist) {
+        inst = a.list[slot];
+        o = a.off[inst];
+        n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
+        if (n > kTiny) {
+            // beyond the first a.cap list entries the host only had an upper bound: chain_quadratic takes those
+            if (slot < a.cap) atomicOr(a.status, 2); // the host's size bound was wrong: fail the call
+            n = -1;
+        }
+        if (n == 0) { a.len[inst] = 0; a.value[inst] = -1.0; }
+    }
+    for (int i = 0; i < n; i++) {
+        sc[i * 64 + lane] = a.c[o + i]; sd[i * 64 + lane] = a.d[o + i]; sV[i * 64 + lane] = a.val[o + i];
+    }
+    int nmax = n;
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) { const int t = __shfl_xor(nmax, w, 64); nmax = t > nmax ? t : nmax; }
+    const int thr = a.thr;
+    for (int j = 0; j < nmax; j++) {
+        if (j >= n) continue;
+        const int cj = sc[j * 64 + lane];
+        const double vj = sV[j * 64 + lane];
+        Cand T = {0.0, -1, 0}, I = {0.0, -1, 0};
+        for (int jp = 0; jp < j; jp++) {
+            const int dj = sd[jp * 64 + lane];
+            const double Cp = sC[jp * 64 + lane];
+            if (dj < cj) {
+                double v = __dsub_rn(Cp, __dmul_rn(0.1, (double)(cj - dj - 1)));
+                Cand t = {v, jp, 1};
+                T = better_hi(T, t);
+            }
+            if (cj <= dj && dj <= cj - 1 + thr) {
+                double ov = (double)(dj - cj + 1);
+                double v = __dadd_rn(Cp, __dsub_rn(__dsub_rn(vj, ov), __dmul_rn(0.1, ov)));
+                Cand t = {v, jp, 1};
+                I = better_hi(I, t);
+            }
+        }
+        const double Ca = __dadd_rn(T.has ? T.v : 0.0, vj);
+        const double Cb = I.has ? I.v : 0.0;
+        if (Ca >= Cb) { sC[j * 64 + lane] = Ca; sp[j * 64 + lane] = T.has ? T.idx : -1; }
+        else { sC[j * 64 + lane] = Cb; sp[j * 64 + lane] = I.has ? I.idx : -1; }
+    }
+    if (n <= 0) return;
+    Cand B = {0.0, -1, 0};
+    for (int i = 0; i < n; i++) { Cand t = {sC[i * 64 + lane], i, 1}; B = better_lo(B, t); }
+    int len = 0;
+    for (int j = B.idx; j >= 0; j = sp[j * 64 + lane]) len++;
+    int w = len;
+    for (int j = B.idx; j >= 0; j = sp[j * 64 + lane]) a.idx[o + (--w)] = j;
+    a.len[inst] = len;
+    a.value[inst] = B.v;
 }
 
 // ---- n log n -------------------------------------------------------------------------------------
@@ -412,6 +484,8 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     const int thr_s = overlap_small < 0 ? ctx->cfg.overlap_small : overlap_small;
     const int thr_l = overlap_large < 0 ? ctx->cfg.overlap_large : overlap_large;
     std::vector<int32_t> small, big, tree;
+    std::vector<int32_t> tiny_n[kTiny + 1]; // MAM instances of at most kTiny entries, by size
+    size_t n_tiny = 0;
     int32_t max_big = 0, max_tree = 0;
     for (int32_t i = 0; i < n_inst; i++) {
         const int32_t n = h_cnt[i];
@@ -421,7 +495,8 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
         if (use_tree && n > 0) {
             if (!nam && thr_l < 1) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: n log n solver needs overlap threshold >= 1");
             tree.push_back(i); max_tree = std::max<int32_t>(max_tree, n);
-        } else if (n <= kQuadSmall) small.push_back(i);
+        } else if (!nam && n <= kTiny) { tiny_n[n].push_back(i); n_tiny++; }
+        else if (n <= kQuadSmall) small.push_back(i);
         else { big.push_back(i); max_big = std::max<int32_t>(max_big, n); }
     }
     if ((size_t)max_big * qstride > (size_t)kLdsBudget)
@@ -444,6 +519,8 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     if (d_status_out) *d_status_out = d_status;
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_status, 0, 4, s));
     ch.h_list.clear();
+    ch.h_list.reserve(ni);
+    for (int n = kTiny; n >= 0; n--) ch.h_list.insert(ch.h_list.end(), tiny_n[n].begin(), tiny_n[n].end());
     ch.h_list.insert(ch.h_list.end(), small.begin(), small.end());
     ch.h_list.insert(ch.h_list.end(), big.begin(), big.end());
     ch.h_list.insert(ch.h_list.end(), tree.begin(), tree.end());
@@ -465,14 +542,25 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     a.val = d_val; a.idx = d_idx; a.len = d_len; a.value = d_value;
     a.status = d_status;
     if (nam) { a.nam = 1; a.max_intron = nam->d_max_intron; a.C_out = nam->d_C; a.trace_out = nam->d_trace; }
+    // with device-side counts the host sizes are only upper bounds: the lane-per-instance kernel then also looks
+    // at the `small` instances and takes those that turn out tiny; chain_quadratic skips them
+    const bool bounds_only = !nam && d_cnt != nullptr;
+    const size_t n_tiny_launch = n_tiny + (bounds_only ? small.size() : 0);
+    if (n_tiny_launch > 0) {
+        a.thr = thr_s; a.list = d_list; a.nlist = (int32_t)n_tiny_launch; a.cap = (int32_t)n_tiny;
+        hipLaunchKernelGGL(chain_tiny, dim3((unsigned)((n_tiny_launch + 63) / 64)), dim3(64), 0, s, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    a.skip_tiny = bounds_only ? 1 : 0;
     if (!small.empty()) {
-        a.thr = thr_s; a.list = d_list; a.nlist = (int32_t)small.size(); a.cap = kQuadSmall;
+        a.thr = thr_s; a.list = d_list + n_tiny; a.nlist = (int32_t)small.size(); a.cap = kQuadSmall;
         int blocks = ((int)small.size() + 3) / 4;
         hipLaunchKernelGGL(chain_quadratic, dim3(blocks), dim3(256), (size_t)4 * kQuadSmall * qstride, s, a);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
+    a.skip_tiny = 0;
     if (!big.empty()) {
-        a.thr = thr_s; a.list = d_list + small.size(); a.nlist = (int32_t)big.size(); a.cap = max_big;
+        a.thr = thr_s; a.list = d_list + n_tiny + small.size(); a.nlist = (int32_t)big.size(); a.cap = max_big;
         size_t shmem = (size_t)max_big * qstride;
         if (shmem > 64 * 1024)
             ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_quadratic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -480,7 +568,7 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     if (!tree.empty()) {
-        a.thr = thr_l; a.list = d_list + small.size() + big.size(); a.nlist = (int32_t)tree.size(); a.cap = tree_leaves;
+        a.thr = thr_l; a.list = d_list + n_tiny + small.size() + big.size(); a.nlist = (int32_t)tree.size(); a.cap = tree_leaves;
         a.work = ch.work.as<uint8_t>(); a.work_off = d_workoff;
         const void *fn = nam ? (const void *)chain_nlogn<true> : (const void *)chain_nlogn<false>;
         if (tree_lds > 64 * 1024)
