@@ -28,3 +28,8 @@ for lo, hi in [(0, 22), (23, 54), (55, 118), (119, 246), (247, 374), (375, 10**9
     m = hit & (ed >= lo) & (ed <= hi)
     if m.any():
         print("ed %d..%d: hits %d  sum L %d  mean L %.0f  max L %d" % (lo, hi, m.sum(), L[m].sum(), L[m].mean(), L[m].max()))
+res = ctx.mam_fetch()
+nm = np.asarray(res["n_mam"])
+print("instances", len(nm), "MAMs", int(nm.sum()), "mean", nm.mean(), "max", nm.max())
+for b in (0, 4, 8, 16, 24, 32, 48, 64, 128, 256):
+    print("  n_mam <= %d: %.4f   share of sum n^2 above: %.3f" % (b, (nm <= b).mean(), (nm[nm > b].astype(np.float64) ** 2).sum() / max(1.0, (nm.astype(np.float64) ** 2).sum())))

@@ -79,7 +79,7 @@ struct ChainArgs {
     int32_t *trace_out;        // same layout, trace[0] = -1
 };
 
-constexpr int kTiny = 16; // largest instance of the lane-per-instance kernel (chain_tiny)
+constexpr int kTiny = 32; // largest instance of the lane-per-instance kernel (chain_tiny)
 
 // ---- quadratic ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
@@ -185,8 +185,9 @@ __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
 // size, so the lanes of a wavefront run equally long.
 __global__ void __launch_bounds__(64) chain_tiny(ChainArgs a)
 {
-    __shared__ double sC[kTiny * 64], sV[kTiny * 64];
-    __shared__ int32_t sc[kTiny * 64], sd[kTiny * 64], sp[kTiny * 64];
+    __shared__ double sC[kTiny * 64];
+    __shared__ int32_t sd[kTiny * 64];
+    __shared__ int8_t sp[kTiny * 64];
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     int inst = 0, n = 0;
@@ -202,17 +203,19 @@ __global__ void __launch_bounds__(64) chain_tiny(ChainArgs a)
         }
         if (n == 0) { a.len[inst] = 0; a.value[inst] = -1.0; }
     }
-    for (int i = 0; i < n; i++) {
-        sc[i * 64 + lane] = a.c[o + i]; sd[i * 64 + lane] = a.d[o + i]; sV[i * 64 + lane] = a.val[o + i];
-    }
+    for (int i = 0; i < n; i++) sd[i * 64 + lane] = a.d[o + i];
     int nmax = n;
 #pragma unroll
     for (int w = 32; w > 0; w >>= 1) { const int t = __shfl_xor(nmax, w, 64); nmax = t > nmax ? t : nmax; }
     const int thr = a.thr;
+    // c and val of MAM j are read once: fetched one j ahead, under the inner loop
+    int c_next = n > 0 ? a.c[o] : 0;
+    double v_next = n > 0 ? a.val[o] : 0.0;
     for (int j = 0; j < nmax; j++) {
         if (j >= n) continue;
-        const int cj = sc[j * 64 + lane];
-        const double vj = sV[j * 64 + lane];
+        const int cj = c_next;
+        const double vj = v_next;
+        if (j + 1 < n) { c_next = a.c[o + j + 1]; v_next = a.val[o + j + 1]; }
         Cand T = {0.0, -1, 0}, I = {0.0, -1, 0};
         for (int jp = 0; jp < j; jp++) {
             const int dj = sd[jp * 64 + lane];
@@ -231,8 +234,8 @@ __global__ void __launch_bounds__(64) chain_tiny(ChainArgs a)
         }
         const double Ca = __dadd_rn(T.has ? T.v : 0.0, vj);
         const double Cb = I.has ? I.v : 0.0;
-        if (Ca >= Cb) { sC[j * 64 + lane] = Ca; sp[j * 64 + lane] = T.has ? T.idx : -1; }
-        else { sC[j * 64 + lane] = Cb; sp[j * 64 + lane] = I.has ? I.idx : -1; }
+        if (Ca >= Cb) { sC[j * 64 + lane] = Ca; sp[j * 64 + lane] = (int8_t)(T.has ? T.idx : -1); }
+        else { sC[j * 64 + lane] = Cb; sp[j * 64 + lane] = (int8_t)(I.has ? I.idx : -1); }
     }
     if (n <= 0) return;
     Cand B = {0.0, -1, 0};
