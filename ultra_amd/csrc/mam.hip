@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     const int64_t c0 = a.cand_off[inst];
     const int C = (int)(a.cand_off[inst + 1] - c0);
     int32_t *ly = lds, *lkept = lds + a.lds_cap, *lact = lds + 2 * a.lds_cap;
+    // what the serial selection loop reads per candidate: kind | e_start | seq_len | seq_id (from LDS, not as a
+    // chain of dependent global loads on one lane)
+    int32_t *lkind = lds + 3 * a.lds_cap, *lstart = lds + 4 * a.lds_cap, *lslen = lds + 5 * a.lds_cap, *lsid = lds + 6 * a.lds_cap;
     const int read_len = a.read_len[inst];
     const long long BIG = 1LL << 32;
     Agg g = {BIG, 0, BIG, 0};
@@ -185,6 +188,7 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
         const int c = (int)(c0 + i);
         const int kind = a.kind[c];
         ly[i] = a.e_stop[c];
+        lkind[i] = kind; lstart[i] = a.e_start[c]; lslen[i] = a.seq_len[c]; lsid[i] = a.seq_id[c];
         int cnt = 0;
         if (kind <= 1) {
             cnt = walk<MODE_COUNT>(a, c, read_len, g, 0, 0, 0);
@@ -208,26 +212,25 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     if (lane == 0) {
         int seg0 = -1, fl0 = -1; // first candidate of the partial-segment / partial-flank loops
         for (int i = 0; i < C;) {
-            const int c = (int)(c0 + i);
-            const int kind = a.kind[c];
+            const int kind = lkind[i];
             if (kind == 2) {
                 if (seg0 < 0) seg0 = i;
                 int pick = -1;
-                if ((long long)a.e_stop[c] <= first_stop) pick = i;
-                else if (last_start <= (long long)a.e_start[c]) pick = i + 1;
-                if (pick >= 0 && a.seq_len[c0 + pick] > 5) {
-                    const int id = a.seq_id[c0 + pick];
+                if ((long long)ly[i] <= first_stop) pick = i;
+                else if (last_start <= (long long)lstart[i]) pick = i + 1;
+                if (pick >= 0 && lslen[pick] > 5) {
+                    const int id = lsid[pick];
                     bool tried = false;
-                    for (int t = seg0; t < i; t++) if (lact[t] && a.seq_id[c0 + t] == id) { tried = true; break; }
+                    for (int t = seg0; t < i; t++) if (lact[t] && lsid[t] == id) { tried = true; break; }
                     if (!tried) lact[pick] = 1;
                 }
                 i += 2;
             } else if (kind >= 4) {
                 if (fl0 < 0) fl0 = i;
-                if (a.seq_len[c] > 5) {
-                    const int id = a.seq_id[c];
+                if (lslen[i] > 5) {
+                    const int id = lsid[i];
                     bool tried = false;
-                    for (int t = fl0; t < i; t++) if (lact[t] && a.seq_id[c0 + t] == id) { tried = true; break; }
+                    for (int t = fl0; t < i; t++) if (lact[t] && lsid[t] == id) { tried = true; break; }
                     if (!tried) lact[i] = 1;
                 }
                 i++;
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     // ---- phase B emission ----
     for (int i = lane; i < C; i += 64) {
         const int c = (int)(c0 + i);
-        if (a.kind[c] >= 2 && lact[i]) lkept[i] = walk<MODE_COUNT>(a, c, read_len, g, 0, 0, 0);
+        if (lkind[i] >= 2 && lact[i]) lkept[i] = walk<MODE_COUNT>(a, c, read_len, g, 0, 0, 0);
     }
     // ---- outermost-partial filter (:530-547) ----
     long long ps = wave_min_ll(g.ps), pe = wave_max_ll(g.pe);
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     pe = pe > maxc ? pe : maxc;
     for (int i = lane; i < C; i += 64) {
         const int c = (int)(c0 + i);
-        if (a.kind[c] >= 2 && lkept[i] > 0) lkept[i] = walk<MODE_KEPT>(a, c, read_len, g, ps, pe, 0);
+        if (lkind[i] >= 2 && lkept[i] > 0) lkept[i] = walk<MODE_KEPT>(a, c, read_len, g, ps, pe, 0);
     }
     __syncthreads();
     // ---- stable sort by y (:553) as a rank over candidates, then the MAM records ----
@@ -367,8 +370,8 @@ extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
                 return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_stage: candidate " + std::to_string(c) + " is narrower than 5 bp but has a pair");
         }
     }
-    if ((size_t)max_c * 12 > (size_t)160 * 1024 - 64)
-        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage: more than 13648 candidates in one instance");
+    if ((size_t)max_c * 28 > (size_t)160 * 1024 - 64)
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage: more than 5849 candidates in one instance");
     int rc = ultra_myers_stage_impl(ctx, in->arena, in->arena_len, np, in->q_off, in->q_len, in->t_off, in->t_len, in->k);
     if (rc != ULTRA_OK) return rc;
     // candidate -> device pair order
@@ -480,7 +483,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     a.mx = m.mx.as<int32_t>(); a.my = m.my.as<int32_t>(); a.mc = m.mc.as<int32_t>(); a.md = m.md.as<int32_t>();
     a.mmsl = m.mmsl.as<int32_t>(); a.mcand = m.mcand.as<int32_t>(); a.mval = m.mval.as<double>(); a.n_mam = m.nmam.as<int32_t>();
     {
-        size_t shmem = (size_t)a.lds_cap * 12;
+        size_t shmem = (size_t)a.lds_cap * 28;
         if (shmem > 64 * 1024)
             ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_mam_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k_mam_build, dim3((unsigned)ni), dim3(64), shmem, s, a);
