@@ -62,15 +62,31 @@ __device__ __forceinline__ double pair_accuracy(const MamArgs &a, int p, int &sp
 //   MODE_COUNT: decides which locations become MAMs (flags), returns their number, updates the aggregates
 //   MODE_KEPT : number of flagged MAMs that survive the outermost-partial filter (:547)
 //   MODE_WRITE: writes the surviving MAMs from slot `o` on, returns how many
-template <int MODE>
-__device__ int walk(const MamArgs &a, int c, int read_len, Agg &g, long long ps, long long pe, int64_t o)
+// The fields of one candidate every pass over it starts from (an instance of at most 64 candidates keeps its
+// lane's candidate in registers across the passes instead of re-reading it through two levels of loads).
+struct CandData {
+    int kind, es, ee, p, pc, nl, ed, seq_len;
+    int64_t lo, cap_off;
+};
+__device__ __forceinline__ CandData load_cand(const MamArgs &a, int c)
 {
-    const int kind = a.kind[c];
-    const int es = a.e_start[c], ee = a.e_stop[c];
+    CandData d;
+    d.kind = a.kind[c]; d.es = a.e_start[c]; d.ee = a.e_stop[c]; d.p = a.pair[c]; d.pc = a.pairc[c];
+    d.seq_len = a.seq_len[c]; d.cap_off = a.cap_off[c];
+    d.nl = 0; d.ed = -1; d.lo = 0;
+    if (d.p >= 0) { d.nl = a.nloc[d.p]; d.ed = a.ed[d.p]; d.lo = a.loc_off[d.p]; }
+    return d;
+}
+
+template <int MODE>
+__device__ int walk(const MamArgs &a, const CandData &cd, int c, int read_len, Agg &g, long long ps, long long pe, int64_t o)
+{
+    const int kind = cd.kind;
+    const int es = cd.es, ee = cd.ee;
     const int width = ee - es;
     const bool st = start_kind(kind), en = end_kind(kind);
-    uint8_t *flag = a.flag + a.cap_off[c];
-    const int p = a.pair[c];
+    uint8_t *flag = a.flag + cd.cap_off;
+    const int p = cd.p;
     int cnt = 0, nl = 0;
     auto take = [&](int s, int e, double val, int msl) {
         if (MODE == MODE_COUNT) {
@@ -90,9 +106,9 @@ __device__ int walk(const MamArgs &a, int c, int read_len, Agg &g, long long ps,
         }
     };
     if (p >= 0) {
-        nl = a.nloc[p];
-        const int ed = a.ed[p];
-        const int64_t lo = a.loc_off[p];
+        nl = cd.nl;
+        const int ed = cd.ed;
+        const int64_t lo = cd.lo;
         if (width >= 9) { // approximate hit (:311-349)
             bool ok = false;
             double acc = 0.0;
@@ -129,12 +145,12 @@ __device__ int walk(const MamArgs &a, int c, int read_len, Agg &g, long long ps,
                     else if (s < smax) { for (int t = 0; t < i; t++) if (a.loc_start[lo + t] == s) { seen = true; break; } }
                     if (s > smax) smax = s;
                     flag[i] = seen ? 0 : 1;
-                    if (!seen) take(s, e, (double)a.seq_len[c], 0);
-                } else if (flag[i]) take(s, e, (double)a.seq_len[c], 0);
+                    if (!seen) take(s, e, (double)cd.seq_len, 0);
+                } else if (flag[i]) take(s, e, (double)cd.seq_len, 0);
             }
         }
     }
-    const int pc = a.pairc[c];
+    const int pc = cd.pc;
     if (pc >= 0) { // read contained in the segment (:374-402)
         if (MODE == MODE_COUNT) {
             bool ok = false;
@@ -183,18 +199,22 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     const long long BIG = 1LL << 32;
     Agg g = {BIG, 0, BIG, 0};
     long long miny = BIG * 4, maxx = -1;
+    const bool one_each = C <= 64; // one candidate per lane: loaded once, kept across the passes
+    CandData mine = {};
+    if (one_each && lane < C) mine = load_cand(a, (int)(c0 + lane));
     // ---- phase A: full segments and flanks (:441-458) ----
     for (int i = lane; i < C; i += 64) {
         const int c = (int)(c0 + i);
-        const int kind = a.kind[c];
-        ly[i] = a.e_stop[c];
-        lkind[i] = kind; lstart[i] = a.e_start[c]; lslen[i] = a.seq_len[c]; lsid[i] = a.seq_id[c];
+        const CandData cd = one_each ? mine : load_cand(a, c);
+        const int kind = cd.kind;
+        ly[i] = cd.ee;
+        lkind[i] = kind; lstart[i] = cd.es; lslen[i] = cd.seq_len; lsid[i] = a.seq_id[c];
         int cnt = 0;
         if (kind <= 1) {
-            cnt = walk<MODE_COUNT>(a, c, read_len, g, 0, 0, 0);
+            cnt = walk<MODE_COUNT>(a, cd, c, read_len, g, 0, 0, 0);
             if (cnt > 0) {
-                if (a.e_stop[c] < miny) miny = a.e_stop[c];
-                if (a.e_start[c] > maxx) maxx = a.e_start[c];
+                if (cd.ee < miny) miny = cd.ee;
+                if (cd.es > maxx) maxx = cd.es;
             }
         }
         lkept[i] = cnt;
@@ -241,7 +261,7 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     // ---- phase B emission ----
     for (int i = lane; i < C; i += 64) {
         const int c = (int)(c0 + i);
-        if (lkind[i] >= 2 && lact[i]) lkept[i] = walk<MODE_COUNT>(a, c, read_len, g, 0, 0, 0);
+        if (lkind[i] >= 2 && lact[i]) lkept[i] = walk<MODE_COUNT>(a, one_each ? mine : load_cand(a, c), c, read_len, g, 0, 0, 0);
     }
     // ---- outermost-partial filter (:530-547) ----
     long long ps = wave_min_ll(g.ps), pe = wave_max_ll(g.pe);
@@ -250,7 +270,7 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     pe = pe > maxc ? pe : maxc;
     for (int i = lane; i < C; i += 64) {
         const int c = (int)(c0 + i);
-        if (lkind[i] >= 2 && lkept[i] > 0) lkept[i] = walk<MODE_KEPT>(a, c, read_len, g, ps, pe, 0);
+        if (lkind[i] >= 2 && lkept[i] > 0) lkept[i] = walk<MODE_KEPT>(a, one_each ? mine : load_cand(a, c), c, read_len, g, ps, pe, 0);
     }
     __syncthreads();
     // ---- stable sort by y (:553) as a rank over candidates, then the MAM records ----
@@ -266,7 +286,7 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
             const int yt = ly[t];
             if (yt < yi || (yt == yi && t < i)) off += lkept[t];
         }
-        walk<MODE_WRITE>(a, (int)(c0 + i), read_len, g, ps, pe, base + off);
+        walk<MODE_WRITE>(a, one_each ? mine : load_cand(a, (int)(c0 + i)), (int)(c0 + i), read_len, g, ps, pe, base + off);
     }
     total = wave_sum_i32(total);
     if (lane == 0) a.n_mam[inst] = total;
