@@ -1519,18 +1519,16 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, a.slots, a.slot_cap, a.loc_off,
                        st.hitoff.as<int64_t>(), a.loc_end, st.locpair.as<int32_t>(), st.hitpairs.as<int32_t>(), n);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare) ----
-    if (h_overflow) {
-        ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
-        for (int b = kBuckets - 1; b >= 0; b--)
-            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), st.buckets[b].n_fwd));
-        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
-    }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
-    // ---- pass 2: start positions ----
+    // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare), and
+    //      pass 2: start positions.  Both are one launch per register bucket on the bucket's own lane, and a
+    //      bucket's start pass only reads end columns of the bucket's own pairs: the two follow each other in the
+    //      lane without a join in between, so one bucket's re-run rides under the other buckets' start passes. ----
     {
         ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
         for (int b = kBuckets - 1; b >= 0; b--) {
+            if (h_overflow)
+                ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), st.buckets[b].n_fwd));
             MyArgs ab = a;
             ab.n_rr = 0;
             int32_t blocks = 0;
