@@ -34,7 +34,7 @@ struct MamArgs {
     const int32_t *read_len;
     const int64_t *fps, *lps; // first_part_stop / last_part_start (classify_read_with_mams.py:194-221)
     double min_acc;
-    int32_t lds_cap;
+    int32_t lds_cap, n_inst;
     // scratch + outputs (slot layout: instance i owns [cap_off[cand_off[i]], cap_off[cand_off[i+1]]))
     uint8_t *flag;
     int32_t *mx, *my, *mc, *md, *mmsl, *mcand;
@@ -166,31 +166,39 @@ __device__ int walk(const MamArgs &a, const CandData &cd, int c, int read_len, A
     return cnt;
 }
 
-__device__ __forceinline__ long long wave_min_ll(long long v)
+// reductions over the VW lanes of one instance (aligned groups of a wavefront: the butterfly stays inside)
+template <int VW> __device__ __forceinline__ long long wave_min_ll(long long v)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { long long w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    for (int o = VW / 2; o > 0; o >>= 1) { long long w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
     return v;
 }
-__device__ __forceinline__ long long wave_max_ll(long long v)
+template <int VW> __device__ __forceinline__ long long wave_max_ll(long long v)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { long long w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    for (int o = VW / 2; o > 0; o >>= 1) { long long w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
     return v;
 }
-__device__ __forceinline__ int wave_sum_i32(int v)
+template <int VW> __device__ __forceinline__ int wave_sum_i32(int v)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = VW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
+// VW lanes per instance: 32 (two instances share a wavefront; an instance has ~18 candidates) unless the largest
+// instance's candidate arrays would not fit LDS twice, then 64.
+template <int VW>
 __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
 {
-    extern __shared__ int32_t lds[];
-    const int inst = blockIdx.x, lane = threadIdx.x;
+    extern __shared__ int32_t lds_all[];
+    const int lane = threadIdx.x % VW, part = threadIdx.x / VW;
+    const int inst_raw = blockIdx.x * (64 / VW) + part;
+    const bool live = inst_raw < a.n_inst;
+    const int inst = live ? inst_raw : 0;
+    int32_t *lds = lds_all + (size_t)part * 7 * a.lds_cap;
     const int64_t c0 = a.cand_off[inst];
-    const int C = (int)(a.cand_off[inst + 1] - c0);
+    const int C = live ? (int)(a.cand_off[inst + 1] - c0) : 0;
     int32_t *ly = lds, *lkept = lds + a.lds_cap, *lact = lds + 2 * a.lds_cap;
     // what the serial selection loop reads per candidate: kind | e_start | seq_len | seq_id (from LDS, not as a
     // chain of dependent global loads on one lane)
@@ -199,11 +207,11 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     const long long BIG = 1LL << 32;
     Agg g = {BIG, 0, BIG, 0};
     long long miny = BIG * 4, maxx = -1;
-    const bool one_each = C <= 64; // one candidate per lane: loaded once, kept across the passes
+    const bool one_each = C <= VW; // one candidate per lane: loaded once, kept across the passes
     CandData mine = {};
     if (one_each && lane < C) mine = load_cand(a, (int)(c0 + lane));
     // ---- phase A: full segments and flanks (:441-458) ----
-    for (int i = lane; i < C; i += 64) {
+    for (int i = lane; i < C; i += VW) {
         const int c = (int)(c0 + i);
         const CandData cd = one_each ? mine : load_cand(a, c);
         const int kind = cd.kind;
@@ -220,8 +228,8 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
         lkept[i] = cnt;
         lact[i] = kind <= 1 ? 1 : 0;
     }
-    miny = wave_min_ll(miny);
-    maxx = wave_max_ll(maxx);
+    miny = wave_min_ll<VW>(miny);
+    maxx = wave_max_ll<VW>(maxx);
     const bool any_a = maxx >= 0;
     // :469-476
     const long long fps = a.fps[inst], lps = a.lps[inst];
@@ -259,16 +267,16 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     }
     __syncthreads();
     // ---- phase B emission ----
-    for (int i = lane; i < C; i += 64) {
+    for (int i = lane; i < C; i += VW) {
         const int c = (int)(c0 + i);
         if (lkind[i] >= 2 && lact[i]) lkept[i] = walk<MODE_COUNT>(a, one_each ? mine : load_cand(a, c), c, read_len, g, 0, 0, 0);
     }
     // ---- outermost-partial filter (:530-547) ----
-    long long ps = wave_min_ll(g.ps), pe = wave_max_ll(g.pe);
-    const long long mind = wave_min_ll(g.mind), maxc = wave_max_ll(g.maxc);
+    long long ps = wave_min_ll<VW>(g.ps), pe = wave_max_ll<VW>(g.pe);
+    const long long mind = wave_min_ll<VW>(g.mind), maxc = wave_max_ll<VW>(g.maxc);
     ps = ps < mind ? ps : mind;
     pe = pe > maxc ? pe : maxc;
-    for (int i = lane; i < C; i += 64) {
+    for (int i = lane; i < C; i += VW) {
         const int c = (int)(c0 + i);
         if (lkind[i] >= 2 && lkept[i] > 0) lkept[i] = walk<MODE_KEPT>(a, one_each ? mine : load_cand(a, c), c, read_len, g, ps, pe, 0);
     }
@@ -276,7 +284,7 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
     // ---- stable sort by y (:553) as a rank over candidates, then the MAM records ----
     const int64_t base = a.cap_off[c0];
     int total = 0;
-    for (int i = lane; i < C; i += 64) {
+    for (int i = lane; i < C; i += VW) {
         const int k = lkept[i];
         if (k <= 0) continue;
         total += k;
@@ -288,8 +296,8 @@ __global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
         }
         walk<MODE_WRITE>(a, one_each ? mine : load_cand(a, (int)(c0 + i)), (int)(c0 + i), read_len, g, ps, pe, base + off);
     }
-    total = wave_sum_i32(total);
-    if (lane == 0) a.n_mam[inst] = total;
+    total = wave_sum_i32<VW>(total);
+    if (lane == 0 && live) a.n_mam[inst] = total;
 }
 
 __global__ void k_cand_cap(const int32_t *pair, const int32_t *pairc, const int32_t *nloc, uint64_t *cap, int32_t n)
@@ -499,14 +507,19 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     a.cap_off = m.capoff.as<int64_t>(); a.cand_off = m.candoff.as<int64_t>(); a.read_len = m.readlen.as<int32_t>();
     a.fps = m.fps.as<int64_t>(); a.lps = m.lps.as<int64_t>(); a.min_acc = min_acc;
     a.lds_cap = std::max<int32_t>(m.max_cand, 1);
+    a.n_inst = ni;
     a.flag = m.flag.as<uint8_t>();
     a.mx = m.mx.as<int32_t>(); a.my = m.my.as<int32_t>(); a.mc = m.mc.as<int32_t>(); a.md = m.md.as<int32_t>();
     a.mmsl = m.mmsl.as<int32_t>(); a.mcand = m.mcand.as<int32_t>(); a.mval = m.mval.as<double>(); a.n_mam = m.nmam.as<int32_t>();
     {
         size_t shmem = (size_t)a.lds_cap * 28;
-        if (shmem > 64 * 1024)
-            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_mam_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_mam_build, dim3((unsigned)ni), dim3(64), shmem, s, a);
+        if (shmem * 2 <= 64 * 1024) {
+            hipLaunchKernelGGL(k_mam_build<32>, dim3((unsigned)((ni + 1) / 2)), dim3(64), shmem * 2, s, a);
+        } else {
+            if (shmem > 64 * 1024)
+                ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_mam_build<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL(k_mam_build<64>, dim3((unsigned)ni), dim3(64), shmem, s, a);
+        }
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[1], s));
