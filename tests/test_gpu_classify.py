@@ -121,6 +121,38 @@ def test_low_complexity_reads_many_locations(ctx):
         assert _same(classify_port.classify(sol, *idx, read, None, 0.6), g)
 
 
+def test_many_candidates_per_instance(ctx):
+    """A gene of 1 300 short segments: every instance has more candidates than the two-instances-per-wavefront form
+    of the MAM kernel keeps in LDS, so the batch takes the wavefront-per-instance form (several candidates per lane)."""
+    from array import array
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd.synth import Mem, key_of
+    rng = np.random.RandomState(8)
+    seg, flank, p2s, s2g, g2s = {}, {}, {}, {}, {"g": array('L')}
+    pos, segs = 1000, []
+    for i in range(1300):
+        ln = int(rng.choice([9, 10, 12, 15, 20, 30]))
+        s = helpers.rand_seq(rng, ln, "ACGT")
+        k = key_of(1, pos, pos + ln)
+        seg[k] = s; s2g[k] = {"g"}; p2s[k] = array('L', [1, pos, pos + ln]); g2s["g"].extend([1, pos, pos + ln])
+        segs.append((pos, pos + ln, s))
+        pos += ln + 50
+    insts = []
+    for r in range(6):
+        picks = sorted(rng.choice(len(segs), size=12, replace=False))
+        read = "".join(segs[i][2] for i in picks) + helpers.rand_seq(rng, 40, "ACGT")
+        a, b, _ = segs[picks[0]]
+        insts.append((read, [Mem(a, b - 1, 0, b - a - 1, b - a, 0, "1^%d^%d" % (a, b))]))
+    idx = (seg, flank, p2s, s2g, g2s)
+    got = stage.main_batch([(sol, read) for read, sol in insts], *idx, min_acc=0.6, ctx=ctx)
+    n_mams = 0
+    for (read, sol), g in zip(insts, got):
+        assert _same(classify_port.classify(sol, *idx, read, None, 0.6), g)
+        n_mams += len(g[2])
+    assert n_mams > 0
+
+
 def test_single_instance_signatures(ctx):
     from oracle import classify_port, cport
     from ultra_amd import classify_read_with_mams as stage
