@@ -42,11 +42,11 @@ def test_reference_switch_rule(ctx):
 
 
 def test_lane_per_instance_kernel(ctx):
-    """Instances of at most 32 MAMs take the lane-per-instance kernel, larger ones in the same batch the
+    """Instances of at most 48 MAMs take the lane-per-instance kernel, larger ones in the same batch the
     wavefront-per-instance one: sizes around that limit, mixed within a wavefront, short reads (many ties and
     overlaps) and two overlap thresholds."""
     rng = np.random.RandomState(6)
-    sizes = [int(s) for s in rng.randint(0, 40, size=1500)] + [31, 32, 33, 32, 0, 1, 32, 33]
+    sizes = [int(s) for s in rng.randint(0, 60, size=1500)] + [47, 48, 49, 48, 0, 1, 48, 49]
     _compare(ctx, *_batch(rng, sizes, [40, 100, 300]), solver=0)
     _compare(ctx, *_batch(rng, sizes[:400], [60, 200]), solver=1, overlap_small=3)
 

@@ -79,7 +79,7 @@ struct ChainArgs {
     int32_t *trace_out;        // same layout, trace[0] = -1
 };
 
-constexpr int kTiny = 32; // largest instance of the lane-per-instance kernel (chain_tiny)
+constexpr int kTiny = 48; // largest instance of the lane-per-instance kernel (chain_tiny)
 
 // ---- quadratic ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
