@@ -1,6 +1,6 @@
 """Development aid: distribution of hits over the traceback classes for the bench workload (run on the GPU box)."""
 import os
-os.environ["GPU_MAX_HW_QUEUES"] = "8"
+os.environ["GPU_MAX_HW_QUEUES"] = "8"  # fixed literal, within the pool limit
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

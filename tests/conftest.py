@@ -1,13 +1,15 @@
 import os
 import sys
 
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("ULTRA_HW_QUEUES", "8")  # before the first HIP call: one hardware queue per launch lane
-
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+from ultra_amd import hwq  # noqa: E402
+
+hwq.export_hw_queues()  # before the first HIP call: one hardware queue per launch lane (ULTRA_HW_QUEUES, clamped)
 
 
 def pytest_configure(config):

@@ -59,6 +59,34 @@ def make_pairs(rng, n_pairs, qlen_range, tlen_range, planted=0.5, rates=(0.0, 0.
         np.array(t_len, np.int32), np.array(ks, np.int32)
 
 
+def _dp_rows(q, t, free_start):
+    """Unit-cost DP of q (rows) against t (columns), row by row with numpy; returns the last row D[m][0..n].
+    free_start: D[0][j] = 0 (semi-global) instead of j (global)."""
+    q = np.frombuffer(q.encode(), np.uint8) if isinstance(q, str) else np.asarray(q, np.uint8)
+    t = np.frombuffer(t.encode(), np.uint8) if isinstance(t, str) else np.asarray(t, np.uint8)
+    n = len(t)
+    idx = np.arange(n + 1, dtype=np.int64)
+    prev = np.zeros(n + 1, np.int64) if free_start else idx.copy()
+    for i in range(1, len(q) + 1):
+        cur = np.empty(n + 1, np.int64)
+        cur[0] = i
+        cur[1:] = np.minimum(prev[:-1] + (t != q[i - 1]), prev[1:] + 1)
+        # horizontal moves: cur[j] = min over j' <= j of cur[j'] + (j - j')
+        cur = np.minimum.accumulate(cur - idx) + idx
+        prev = cur
+    return prev
+
+
+def nw_distance(q, t):
+    """Global edit distance (plain DP, independent of the oracle and of the library)."""
+    return int(_dp_rows(q, t, False)[-1])
+
+
+def semiglobal_bottom_row(q, t):
+    """D[m][j] for end columns j = 0 .. n-1 of the infix search (0-based inclusive end), plain DP."""
+    return _dp_rows(q, t, True)[1:]
+
+
 def make_mams(rng, n, readlen, ties):
     """Random MAM instance sorted by y: arrays x, y, c, d, val."""
     rows = []

@@ -303,3 +303,31 @@ def test_stage_properties_at_bench_scale(ctx):
     for i in range(0, len(insts), 997):
         read, sol, _ = insts[i]
         assert _same(classify_port.classify(sol, *idx, read, None, 0.6), out[i])
+
+
+def test_restaging_pairs_invalidates_the_mam_batch(ctx):
+    """A MAM batch's candidate arrays are permuted for the pair batch it staged itself.  Staging other pairs in the
+    same context (ultra_myers_stage, or ultra_myers_hw_batch as edlib_shim.align does) must make a repeated
+    ultra_mam_run answer ULTRA_E_STATE instead of reading stale pair indices."""
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import lib, synth
+    w = synth.make_world(seed=22, n_genes=10)
+    insts = synth.make_instances(w, 40, seed=5)
+    batch = stage.prepare_batch([(sol, read) for read, sol, _ in insts], *w.index())
+    small = helpers.make_pairs(np.random.RandomState(1), 5, (9, 40), (50, 100))
+    for restage in ("stage", "hw_batch"):
+        stage.stage_batch(ctx, batch)
+        stage.run_staged(ctx, 0.6)
+        first = ctx.mam_fetch()
+        if restage == "stage":
+            ctx.myers_stage(*small)
+        else:
+            ctx.myers_hw_batch(*small)
+        with pytest.raises(lib.UltraError) as err:
+            ctx.mam_run(0.6)
+        assert err.value.code == -6  # ULTRA_E_STATE
+        stage.stage_batch(ctx, batch)   # staging again recovers
+        stage.run_staged(ctx, 0.6)
+        again = ctx.mam_fetch()
+        for k in first:
+            assert np.array_equal(np.asarray(first[k]), np.asarray(again[k])), k

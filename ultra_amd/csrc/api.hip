@@ -39,8 +39,13 @@ int ultra_ctx_create(int device, const ultra_cfg *cfg, ultra_ctx **out)
     if (ctx->cfg.launch_lanes == 0) {
         // one lane per hardware queue of the process: HIP's default is 4, GPU_MAX_HW_QUEUES raises it
         const char *q = getenv("GPU_MAX_HW_QUEUES");
-        const int nq = q ? atoi(q) : 4;
-        ctx->cfg.launch_lanes = nq < 1 ? 1 : nq > kLanes ? kLanes : nq;
+        long nq = 4;
+        if (q && *q) {
+            char *endp = nullptr;
+            const long v = strtol(q, &endp, 10);
+            if (endp != q && *endp == 0 && v >= 1) nq = v; // anything else: HIP's own default
+        }
+        ctx->cfg.launch_lanes = nq > kLanes ? kLanes : (int)nq;
     }
     if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) { delete ctx; return ULTRA_E_HIP; }
     // the code object is built for gfx950 only; refuse anything else loudly
@@ -88,6 +93,9 @@ int ultra_myers_stage(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, in
                       const int32_t *k)
 {
     if (!ctx) return ULTRA_E_ARG;
+    // the MAM stage's candidate arrays are permuted for the pair batch it staged itself: a new pair batch
+    // invalidates them (ultra_mam_run then answers ULTRA_E_STATE instead of reading stale indices)
+    ctx->mam.staged = false; ctx->mam.ran = false;
     return ultra_myers_stage_impl(ctx, arena, arena_len, n_pairs, q_off, q_len, t_off, t_len, k);
 }
 
@@ -139,6 +147,9 @@ static int fetch_impl(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
     std::vector<int32_t> h_ed(n), h_nl(n), h_fi(n), h_no;
     std::vector<int64_t> h_lo((size_t)n + 1);
     std::vector<int32_t> h_ls((size_t)st.total_loc), h_le((size_t)st.total_loc);
+    std::vector<uint8_t> h_ops;
+    std::vector<int64_t> s_opsoff; // sorted-order offsets used on the device
+    ultra_drain_guard drain(ctx); // declared after the vectors: they must outlive every copy enqueued below, also on an error return
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_ed.data(), st.ed.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_nl.data(), st.nloc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_fi.data(), st.firstins.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -147,8 +158,6 @@ static int fetch_impl(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_ls.data(), st.locstart.p, (size_t)st.total_loc * 4, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_le.data(), st.locend.p, (size_t)st.total_loc * 4, hipMemcpyDeviceToHost, s));
     }
-    std::vector<uint8_t> h_ops;
-    std::vector<int64_t> s_opsoff; // sorted-order offsets used on the device
     if (ops) {
         h_no.resize(n);
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_no.data(), st.nops.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -159,6 +168,7 @@ static int fetch_impl(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_ops.data(), st.ops.p, (size_t)s_opsoff[n], hipMemcpyDeviceToHost, s));
     }
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    drain.dismiss();
     // un-permute: results are stored in (class, target length) order on the device
     for (int32_t i = 0; i < n; i++) { int32_t p = st.perm[i]; ed[p] = h_ed[i]; n_loc[p] = h_nl[i]; first_ins[p] = h_fi[i]; }
     loc_off[0] = 0;
@@ -197,6 +207,7 @@ int ultra_myers_hw_batch(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len,
                          int32_t *first_ins, uint8_t *ops, const int64_t *ops_off, int32_t *n_ops)
 {
     if (!ctx) return ULTRA_E_ARG;
+    ctx->mam.staged = false; ctx->mam.ran = false; // see ultra_myers_stage
     int rc = ultra_myers_stage_impl(ctx, arena, arena_len, n_pairs, q_off, q_len, t_off, t_len, k);
     if (rc != ULTRA_OK) return rc;
     bool want_ops = ops != nullptr;

@@ -151,6 +151,22 @@ static inline hipError_t ultra_join(ultra_ctx *ctx)
     return e;
 }
 
+// Error paths must not return with work in flight: host vectors that async copies still read or write would be
+// destroyed under the DMA, and the next call would race with the aux lanes.  Armed after the first enqueue of a
+// call, dismissed on its normal return; on any other return it waits (best effort) for every lane.
+struct ultra_drain_guard {
+    ultra_ctx *ctx;
+    bool armed = true;
+    explicit ultra_drain_guard(ultra_ctx *c) : ctx(c) {}
+    void dismiss() { armed = false; }
+    ~ultra_drain_guard()
+    {
+        if (!armed) return;
+        for (int i = 0; i < kAuxStreams; i++) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    }
+};
+
 static inline int ultra_fail(ultra_ctx *ctx, int code, const std::string &msg)
 {
     if (ctx) ctx->err = msg;

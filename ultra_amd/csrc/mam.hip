@@ -487,6 +487,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     if (rc != ULTRA_OK) return rc;
     if (ni == 0) { m.ran = true; return ULTRA_OK; }
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ultra_drain_guard drain(ctx);
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[0], s));
     m.total_cap = m.pinned_base[ni];
     const size_t T = (size_t)std::max<int64_t>(m.total_cap, 1);
@@ -572,6 +573,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&m.ms[0], m.ev[0], m.ev[1]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&m.ms[1], m.ev[2], m.ev[3]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&m.ms[2], m.ev[3], m.ev[4]));
+    drain.dismiss();
     m.ran = true;
     return ULTRA_OK;
 }
@@ -606,6 +608,7 @@ extern "C" int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out)
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_fetch: null chain array");
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    ultra_drain_guard drain(ctx); // host vectors below must outlive the copies, also on an error return
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->value, m.value.p, (size_t)ni * 8, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->chain_off, m.chainoff.p, ((size_t)ni + 1) * 8, hipMemcpyDeviceToHost, s));
     if (TC > 0) {
@@ -628,6 +631,7 @@ extern "C" int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out)
         const size_t T = (size_t)m.total_cap;
         std::vector<int32_t> hx(T), hy(T), hc(T), hd(T), hm(T), hk(T);
         std::vector<double> hv(T);
+        ultra_drain_guard drain_all(ctx); // after the vectors it protects
         if (T > 0) {
             ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hx.data(), m.mx.p, T * 4, hipMemcpyDeviceToHost, s));
             ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hy.data(), m.my.p, T * 4, hipMemcpyDeviceToHost, s));
@@ -650,8 +654,10 @@ extern "C" int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out)
             }
         }
         out->mam_off[ni] = w;
+        drain_all.dismiss();
     }
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    drain.dismiss();
     return ULTRA_OK;
 }
 

@@ -926,12 +926,8 @@ __global__ void __launch_bounds__(64) myers_band32(MyArgs a, const int32_t *item
         auto qblock = [&](int r) { return (r >= 0 && r < m) ? load8(q + r) : (uint64_t)0; };
         auto prefetch = [&](int cn) {
             pref_c = cn;
-#ifdef BAND32_DIAG
-            twn = 0x0102030001020300ull + cn; qwn = 0x0302010003020100ull + cn;
-#else
             twn = (cn >= 0 && cn < L) ? load8(t + cn) : 0;
             qwn = qblock(TOP + 1 + off + cn);
-#endif
         };
         auto push_row = [&](uint32_t code1) {
 #pragma unroll
@@ -1471,6 +1467,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     a.loc_off = st.locoff.as<int64_t>(); a.hit_pairs = st.hitpairs.as<int32_t>(); a.first_ins = st.firstins.as<int32_t>();
     a.n_ops = st.nops.as<int32_t>();
 
+    ultra_drain_guard drain(ctx); // any early return below first waits for what has been enqueued
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.firstins.p, 0, (size_t)n * 4, s));
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.nops.p, 0, (size_t)n * 4, s));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[0], s));
@@ -1504,9 +1501,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(dpos, pos.data(), npz * 8, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_gather_bounds, dim3(1), dim3(64), 0, s, st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), dpos, dout, npz);
         std::vector<int64_t> hb((size_t)npz * 2);
+        ultra_drain_guard drain_b(ctx); // pos / hb are copy endpoints
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb.data(), dout, npz * 16, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_overflow, st.bounds.as<int64_t>() + 63, 8, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        drain_b.dismiss();
         for (size_t c = 0; c < st.classes.size(); c++) {
             st.classes[c].lb = hb[2 * c]; st.classes[c].le = hb[2 * (c + 1)];
             st.classes[c].hb = hb[2 * c + 1]; st.classes[c].he = hb[2 * (c + 1) + 1];
@@ -1735,6 +1734,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[3], st.ev[0], st.ev[3]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[4], st.ev[0], st.ev[4]));
     for (auto &bk : st.buckets) { bk.fwd_ms = 0; if (bk.n_fwd > 0) ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&bk.fwd_ms, bk.ev0, bk.ev1)); }
+    drain.dismiss();
     st.ran = true;
     return ULTRA_OK;
 }
