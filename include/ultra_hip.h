@@ -138,6 +138,24 @@ int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
                            int32_t *chain_idx, int32_t *chain_len, double *value);
 
 /*
+ * ultra_chain_mams_batch for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same results, bit for
+ * bit, as ultra_chain_mams_batch above; but every byte of device memory it needs beyond the caller's host arrays
+ * (staging copies of the MAM arrays, launch lists, result vectors, the n log n solver's tree arrays) lives in a fixed
+ * 8 MiB array inside the library image - no hipMalloc / hipFree, no growable context buffers.
+ *   - limit: ultra_chain_noalloc_capacity() bytes; a batch needs about 28 B per MAM + 32 B per instance (+ 28 B per
+ *     MAM of an instance that takes the n log n solver); beyond that the call returns ULTRA_E_CAPACITY and touches
+ *     nothing - split the batch, or use ultra_chain_mams_batch;
+ *   - every GPU the library runs on holds its own copy of the array until the process ends;
+ *   - all calls on one GPU share that GPU's array (whatever the context): calls that overlap on one GPU race.
+ */
+int ultra_chain_mams_batch_noalloc(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
+                                   const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
+                                   const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
+                                   int32_t *chain_idx, int32_t *chain_len, double *value);
+int64_t ultra_chain_noalloc_capacity(void);
+
+/*
  * Batched NAM (seed) colinear chaining - the step before the MAM stage.  Replaces
  *     colinear_solver.read_coverage(mems, max_intron)    (modules/colinear_solver.py:169-272, n < 90)
  *     colinear_solver.n_logn_read_coverage(mems)         (modules/colinear_solver.py:85-167,  n >= 90)

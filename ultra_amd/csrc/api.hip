@@ -56,6 +56,7 @@ int ultra_ctx_create(int device, const ultra_cfg *cfg, ultra_ctx **out)
         ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { ultra_ctx_destroy(ctx); return ULTRA_E_HIP; }
+    if (ultra_chain_scratch_init(ctx) != ULTRA_OK) { ultra_ctx_destroy(ctx); return ULTRA_E_HIP; }
     *out = ctx;
     return ULTRA_OK;
 }

@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <mutex>
 #include <string.h>
 
 namespace {
@@ -480,7 +481,8 @@ void ultra_chain_free(ultra_ctx *ctx)
 int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, const int64_t *d_off, const int32_t *d_cnt,
                        const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
                        int32_t solver, int32_t overlap_small, int32_t overlap_large,
-                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out, const ultra_nam_chain *nam)
+                       int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out, const ultra_nam_chain *nam,
+                       const ultra_chain_ws *ws)
 {
     const size_t qstride = nam ? 24 : 20; // LDS bytes per entry of the quadratic kernel
     if (solver < 0 || solver > 2) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: solver must be 0, 1 or 2");
@@ -515,8 +517,11 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     hipStream_t s = ctx->stream;
     const size_t ni = (size_t)n_inst;
     // device layout of ch.off: work_off | list | status
-    ULTRA_HIP_CHECK(ctx, ch.off.ensure((ni + 1) * 8 + ni * 4 + 64));
-    int64_t *d_workoff = ch.off.as<int64_t>();
+    const size_t aux_bytes = ultra_chain_aux_bytes(n_inst);
+    if (ws) {
+        if (aux_bytes > ws->aux_cap) return ultra_fail(ctx, ULTRA_E_CAPACITY, "chaining: the caller's workspace is too small for the instance lists");
+    } else ULTRA_HIP_CHECK(ctx, ch.off.ensure(aux_bytes));
+    int64_t *d_workoff = ws ? (int64_t *)ws->aux : ch.off.as<int64_t>();
     int32_t *d_list = (int32_t *)(d_workoff + (ni + 1));
     int32_t *d_status = d_list + ni;
     if (d_status_out) *d_status_out = d_status;
@@ -536,7 +541,10 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
         ch.h_workoff[t + 1] = ch.h_workoff[t] + ((bytes + 15) & ~(int64_t)15);
     }
     if (!tree.empty()) {
-        ULTRA_HIP_CHECK(ctx, ch.work.ensure((size_t)ch.h_workoff.back() + 16));
+        if (ws) {
+            if ((size_t)ch.h_workoff.back() + 16 > ws->work_cap)
+                return ultra_fail(ctx, ULTRA_E_CAPACITY, "chaining: the caller's workspace is too small for the n log n solver's trees");
+        } else ULTRA_HIP_CHECK(ctx, ch.work.ensure((size_t)ch.h_workoff.back() + 16));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(d_workoff, ch.h_workoff.data(), ch.h_workoff.size() * 8, hipMemcpyHostToDevice, s));
     }
     ChainArgs a;
@@ -572,7 +580,7 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     }
     if (!tree.empty()) {
         a.thr = thr_l; a.list = d_list + n_tiny + small.size() + big.size(); a.nlist = (int32_t)tree.size(); a.cap = tree_leaves;
-        a.work = ch.work.as<uint8_t>(); a.work_off = d_workoff;
+        a.work = ws ? ws->work : ch.work.as<uint8_t>(); a.work_off = d_workoff;
         const void *fn = nam ? (const void *)chain_nlogn<true> : (const void *)chain_nlogn<false>;
         if (tree_lds > 64 * 1024)
             ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
@@ -632,6 +640,107 @@ extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int6
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
     if (status != 0)
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch: an instance reached the reference's 'BUG' state "
+                                            "(empty range-query node set); check that c <= d for every MAM");
+    return ULTRA_OK;
+}
+
+// ---- the one entry point that allocates nothing ----------------------------------------------------------------
+// ultra_chain_mams_batch needs device memory beyond its inputs and outputs: staging copies of the MAM arrays, the
+// launch lists, the result vectors and the search-tree arrays of the n log n solver.  Callers that must not allocate
+// (HIP graph capture, serving loops, harnesses that forbid hipMalloc) get the same kernels on a fixed buffer that is
+// part of the library's image: every GPU holds its own copy at its own address until the process ends.
+constexpr size_t kNoAllocBytes = (size_t)8 << 20;
+static __device__ __align__(256) uint8_t scratch[kNoAllocBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+uint8_t *g_scratch_ptr[kMaxDevices] = {}; // device address of `scratch` on each GPU (the symbol itself is a host-side stand-in)
+std::mutex g_scratch_mu;
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+} // namespace
+
+// called by ultra_ctx_create with the context's device current
+int ultra_chain_scratch_init(ultra_ctx *ctx)
+{
+    if (ctx->device < 0 || ctx->device >= kMaxDevices) return ULTRA_OK; // no-alloc entry point unavailable there
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[ctx->device]) {
+        uint8_t *ptr = nullptr;
+        ULTRA_HIP_CHECK(ctx, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[ctx->device] = ptr;
+    }
+    ctx->ch.fixed = g_scratch_ptr[ctx->device];
+    return ULTRA_OK;
+}
+
+extern "C" int64_t ultra_chain_noalloc_capacity(void) { return (int64_t)kNoAllocBytes; }
+
+extern "C" int ultra_chain_mams_batch_noalloc(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
+                                              const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
+                                              const double *val, int32_t solver, int32_t overlap_small, int32_t overlap_large,
+                                              int32_t *chain_idx, int32_t *chain_len, double *value)
+{
+    if (!ctx) return ULTRA_E_ARG;
+    if (n_inst < 0 || (n_inst > 0 && (!inst_off || !chain_len || !value)))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch_noalloc: null pointer or negative instance count");
+    if (n_inst == 0) return ULTRA_OK;
+    const int64_t total = inst_off[n_inst];
+    if (inst_off[0] != 0 || total < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch_noalloc: inst_off must start at 0");
+    if (total > 0 && (!x || !y || !c || !d || !val || !chain_idx))
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch_noalloc: null MAM array");
+    uint8_t *const base = ctx->ch.fixed; // the device address, never the symbol's name
+    if (!base) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_chain_mams_batch_noalloc: no fixed buffer on this device");
+    // ---- sizes first: nothing is touched when the batch does not fit ----
+    const size_t nt = (size_t)std::max<int64_t>(total, 1), ni = (size_t)n_inst;
+    size_t tree_bytes = 16;
+    for (int32_t i = 0; i < n_inst; i++) {
+        const int64_t n = inst_off[i + 1] - inst_off[i];
+        if (n < 0 || n > 0x7fffffff) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch_noalloc: inst_off must be non-decreasing");
+        if (n > 0 && (solver == 2 || (solver == 0 && n > ctx->cfg.chain_switch_n))) tree_bytes += (size_t)(((n + 1) * 12 + n * 16 + 15) & ~(int64_t)15);
+    }
+    size_t at = 0;
+    auto carve = [&](size_t bytes) { const size_t o = at; at += up256(bytes); return o; };
+    const size_t o_ioff = carve((ni + 1) * 8), o_x = carve(nt * 4), o_y = carve(nt * 4), o_c = carve(nt * 4), o_d = carve(nt * 4),
+                 o_val = carve(nt * 8), o_idx = carve(nt * 4), o_len = carve(ni * 4 + 16), o_value = carve(ni * 8),
+                 o_aux = carve(ultra_chain_aux_bytes(n_inst)), o_work = carve(tree_bytes);
+    if (at > kNoAllocBytes)
+        return ultra_fail(ctx, ULTRA_E_CAPACITY, "ultra_chain_mams_batch_noalloc: the batch needs " + std::to_string(at) +
+                                                     " bytes of device scratch, the fixed buffer holds " + std::to_string(kNoAllocBytes) +
+                                                     " (about 28 B per MAM + 32 B per instance + 28 B per MAM of an n log n instance); "
+                                                     "split the batch or use ultra_chain_mams_batch");
+    std::vector<int32_t> h_cnt(ni);
+    for (int32_t i = 0; i < n_inst; i++) h_cnt[(size_t)i] = (int32_t)(inst_off[i + 1] - inst_off[i]);
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    ultra_drain_guard drain(ctx);
+    // The buffer keeps the previous call's bytes.  Everything a kernel reads is overwritten below (inputs) or
+    // inside the launch (lists, status word, tree arrays are initialised by their kernel); len / value / idx are
+    // written for every instance before they are copied out, idx only up to len[i] entries per instance.
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(base + o_ioff, inst_off, (ni + 1) * 8, hipMemcpyHostToDevice, s));
+    if (total > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(base + o_x, x, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(base + o_y, y, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(base + o_c, c, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(base + o_d, d, nt * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(base + o_val, val, nt * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(base + o_idx, 0, nt * 4, s)); // entries beyond a chain's length: defined bytes
+    }
+    const ultra_chain_ws ws = {base + o_aux, up256(ultra_chain_aux_bytes(n_inst)), base + o_work, up256(tree_bytes)};
+    int32_t *d_status = nullptr;
+    int rc = ultra_chain_launch(ctx, n_inst, h_cnt.data(), (const int64_t *)(base + o_ioff), nullptr, (const int32_t *)(base + o_x),
+                                (const int32_t *)(base + o_y), (const int32_t *)(base + o_c), (const int32_t *)(base + o_d),
+                                (const double *)(base + o_val), solver, overlap_small, overlap_large, (int32_t *)(base + o_idx),
+                                (int32_t *)(base + o_len), (double *)(base + o_value), &d_status, nullptr, &ws);
+    if (rc != ULTRA_OK) return rc;
+    int32_t status = 0;
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(chain_len, base + o_len, ni * 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(value, base + o_value, ni * 8, hipMemcpyDeviceToHost, s));
+    if (total > 0) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(chain_idx, base + o_idx, nt * 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    drain.dismiss();
+    if (status != 0)
+        return ultra_fail(ctx, ULTRA_E_ARG, "ultra_chain_mams_batch_noalloc: an instance reached the reference's 'BUG' state "
                                             "(empty range-query node set); check that c <= d for every MAM");
     return ULTRA_OK;
 }

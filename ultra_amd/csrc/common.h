@@ -77,6 +77,7 @@ struct MyersState {
 };
 
 struct ChainState {
+    uint8_t *fixed = nullptr;        // device address of chain.hip's fixed scratch array on this context's GPU
     DevBuf ioff, off, x, y, c, d, val, idx, len, value, work, namC, namtrace, intron;
     std::vector<int32_t> h_list;     // kept alive until the stream has consumed them
     std::vector<int64_t> h_workoff;
@@ -184,11 +185,18 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
                            const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                            const int32_t *k);
 int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops);
+// caller-provided device workspace of ultra_chain_launch (instead of the context's growable buffers)
+struct ultra_chain_ws {
+    uint8_t *aux; size_t aux_cap;   // work offsets | launch list | status word: ultra_chain_aux_bytes(n_inst)
+    uint8_t *work; size_t work_cap; // search-tree arrays of the n log n solver
+};
+static inline size_t ultra_chain_aux_bytes(int32_t n_inst) { return ((size_t)n_inst + 1) * 8 + (size_t)n_inst * 4 + 64; }
 int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, const int64_t *d_off, const int32_t *d_cnt,
                        const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
                        int32_t solver, int32_t overlap_small, int32_t overlap_large,
                        int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out,
-                       const ultra_nam_chain *nam = nullptr);
+                       const ultra_nam_chain *nam = nullptr, const ultra_chain_ws *ws = nullptr);
+int ultra_chain_scratch_init(ultra_ctx *ctx);
 // exclusive scan of n 64-bit values on ctx->stream (tmp: scratch, grown as needed)
 hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp);
 void ultra_myers_free(ultra_ctx *ctx);

@@ -21,6 +21,7 @@ EXPORTS = [
     "ultra_cfg_default", "ultra_ctx_create", "ultra_ctx_destroy", "ultra_last_error", "ultra_device_count",
     "ultra_device_info", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
     "ultra_myers_last_timing", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
+    "ultra_chain_mams_batch_noalloc", "ultra_chain_noalloc_capacity",
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
     "ultra_index_create", "ultra_index_destroy", "ultra_plan_create", "ultra_plan_input", "ultra_plan_cands",
     "ultra_plan_destroy", "ultra_plan_last_error",
@@ -109,6 +110,9 @@ def load():
     lib.ultra_myers_class_timing.argtypes = [vp, C.c_int32, i32p, i32p, f64p, C.POINTER(C.c_float), i32p]
     lib.ultra_chain_mams_batch.argtypes = [vp, C.c_int32, i64p, i32p, i32p, i32p, i32p, f64p, C.c_int32, C.c_int32,
                                            C.c_int32, i32p, i32p, f64p]
+    lib.ultra_chain_mams_batch_noalloc.argtypes = lib.ultra_chain_mams_batch.argtypes
+    lib.ultra_chain_noalloc_capacity.argtypes = []
+    lib.ultra_chain_noalloc_capacity.restype = C.c_int64
     lib.ultra_chain_nams_batch.argtypes = [vp, C.c_int32, i64p, i32p, i32p, i32p, i64p, C.c_int32, i64p, i32p, i64p]
     lib.ultra_mam_batch.argtypes = [vp, C.POINTER(MamInput), C.c_double, C.POINTER(MamOutput)]
     lib.ultra_mam_stage.argtypes = [vp, C.POINTER(MamInput)]
@@ -335,17 +339,19 @@ class Context(object):
         return r
 
     # ---- chaining ----------------------------------------------------------------------------
-    def chain_mams_batch(self, inst_off, x, y, c, d, val, solver=0, overlap_small=-1, overlap_large=-1):
+    def chain_mams_batch(self, inst_off, x, y, c, d, val, solver=0, overlap_small=-1, overlap_large=-1, noalloc=False):
+        """noalloc: through ultra_chain_mams_batch_noalloc (fixed device scratch inside the library, no hipMalloc)."""
         inst_off = _arr(inst_off, np.int64)
         x, y, c, d = _arr(x, np.int32), _arr(y, np.int32), _arr(c, np.int32), _arr(d, np.int32)
         val = _arr(val, np.float64)
         ni = len(inst_off) - 1
         idx = np.zeros(max(len(c), 1), np.int32); ln = np.zeros(max(ni, 1), np.int32)
         value = np.zeros(max(ni, 1), np.float64)
-        self._check(self.lib.ultra_chain_mams_batch(self._h, ni, _ptr(inst_off, C.c_int64), _ptr(x, C.c_int32),
-                                                    _ptr(y, C.c_int32), _ptr(c, C.c_int32), _ptr(d, C.c_int32),
-                                                    _ptr(val, C.c_double), solver, overlap_small, overlap_large,
-                                                    _ptr(idx, C.c_int32), _ptr(ln, C.c_int32), _ptr(value, C.c_double)))
+        fn = self.lib.ultra_chain_mams_batch_noalloc if noalloc else self.lib.ultra_chain_mams_batch
+        self._check(fn(self._h, ni, _ptr(inst_off, C.c_int64), _ptr(x, C.c_int32),
+                      _ptr(y, C.c_int32), _ptr(c, C.c_int32), _ptr(d, C.c_int32),
+                      _ptr(val, C.c_double), solver, overlap_small, overlap_large,
+                      _ptr(idx, C.c_int32), _ptr(ln, C.c_int32), _ptr(value, C.c_double)))
         return idx, ln[:ni], value[:ni]
 
     def chain_nams_batch(self, inst_off, y, c, d, max_intron=None, solver=0):
