@@ -139,6 +139,7 @@ static int fetch_impl(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
     const int32_t n = st.n_pairs;
     if (loc_need) *loc_need = st.total_loc;
     if (n == 0) { if (loc_off) loc_off[0] = 0; return ULTRA_OK; }
+    { const int prc = ultra_myers_host_perm(ctx); if (prc != ULTRA_OK) return prc; }
     if (!ed || !n_loc || !loc_off || !first_ins) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_fetch: null output pointer");
     if (st.total_loc > loc_cap || (st.total_loc > 0 && (!loc_start || !loc_end))) {
         return ultra_fail(ctx, ULTRA_E_CAPACITY, "ultra_myers_fetch: location arrays too small, need " + std::to_string(st.total_loc));
@@ -215,6 +216,7 @@ int ultra_myers_hw_batch(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len,
     if (want_ops) {
         if (!ops_off) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_hw_batch: ops given without ops_off");
         MyersState &st = ctx->my;
+        { const int prc = ultra_myers_host_perm(ctx); if (prc != ULTRA_OK) return prc; }
         std::vector<int64_t> s_off((size_t)n_pairs + 1);
         s_off[0] = 0;
         for (int32_t i = 0; i < n_pairs; i++) {

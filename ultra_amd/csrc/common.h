@@ -62,17 +62,18 @@ struct MyersState {
     int32_t n_pairs = 0;
     int64_t N = 0;      // arena length
     int S = 0;          // alphabet size of the batch (distinct bytes)
-    std::vector<int32_t> perm;      // sorted position -> caller's pair index
+    std::vector<int32_t> perm;      // sorted position -> caller's pair index (host copy, fetched on demand)
+    bool perm_on_host = false;
     std::vector<MyersClass> classes;
     MyersBucket buckets[5];
-    std::vector<WorkItem> h_work[5];
-    std::vector<int64_t> h_qoff, h_toff;
-    std::vector<int32_t> h_qlen, h_tlen, h_k;
     double cells = 0;
     float ms[5] = {0, 0, 0, 0, 0};
     int64_t total_loc = 0, total_hit = 0;
     DevBuf seq, rseq, qoff, qlen, toff, tlen, k, ed, nloc, slots, packed, scanned, blocksum, locoff, hitoff,
         locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2;
+    // staging: raw bytes, byte -> code table (+ presence mask), the pairs as the caller ordered them, sort scratch,
+    // sorted position -> caller's index and its inverse, per-class statistics, unsorted work items
+    DevBuf raw, lut, u_qoff, u_qlen, u_toff, u_tlen, u_k, skeys, perm_d, inv_d, stats, worktmp;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -184,6 +185,8 @@ struct ultra_nam_chain {
 int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
                            const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                            const int32_t *k);
+int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs);
+int ultra_myers_host_perm(ultra_ctx *ctx);
 int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops);
 // caller-provided device workspace of ultra_chain_launch (instead of the context's growable buffers)
 struct ultra_chain_ws {

@@ -305,6 +305,13 @@ __global__ void k_cand_cap(const int32_t *pair, const int32_t *pairc, const int3
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) cap[i] = (uint64_t)((pair[i] >= 0 ? nloc[pair[i]] : 0) + (pairc[i] >= 0 ? 1 : 0));
 }
+__global__ void k_remap_pairs(int32_t *pair, int32_t *pairc, const int32_t *inv, int32_t n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (pair[i] >= 0) pair[i] = inv[pair[i]];
+    if (pairc[i] >= 0) pairc[i] = inv[pairc[i]];
+}
 // closes an exclusive scan: out[n] = out[n-1] + in[n-1]
 __global__ void k_scan_close(const uint64_t *in, uint64_t *out, int64_t n)
 {
@@ -402,15 +409,7 @@ extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
         return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage: more than 5849 candidates in one instance");
     int rc = ultra_myers_stage_impl(ctx, in->arena, in->arena_len, np, in->q_off, in->q_len, in->t_off, in->t_len, in->k);
     if (rc != ULTRA_OK) return rc;
-    // candidate -> device pair order
     const MyersState &my = ctx->my;
-    std::vector<int32_t> inv((size_t)np);
-    for (int32_t i = 0; i < np; i++) inv[(size_t)my.perm[(size_t)i]] = i;
-    std::vector<int32_t> h_pair((size_t)std::max(nc, 1)), h_pairc((size_t)std::max(nc, 1));
-    for (int32_t c = 0; c < nc; c++) {
-        h_pair[c] = in->cand_pair[c] >= 0 ? inv[(size_t)in->cand_pair[c]] : -1;
-        h_pairc[c] = in->cand_pair_contained[c] >= 0 ? inv[(size_t)in->cand_pair_contained[c]] : -1;
-    }
     hipStream_t s = ctx->stream;
     const size_t NC = (size_t)std::max(nc, 1), NI = (size_t)std::max(ni, 1);
     ULTRA_HIP_CHECK(ctx, m.kind.ensure(NC)); ULTRA_HIP_CHECK(ctx, m.estart.ensure(NC * 4)); ULTRA_HIP_CHECK(ctx, m.estop.ensure(NC * 4));
@@ -426,8 +425,12 @@ extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.kind.p, in->cand_kind, NC, hipMemcpyHostToDevice, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.estart.p, in->cand_e_start, NC * 4, hipMemcpyHostToDevice, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.estop.p, in->cand_e_stop, NC * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pair.p, h_pair.data(), NC * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pairc.p, h_pairc.data(), NC * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pair.p, in->cand_pair, NC * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pairc.p, in->cand_pair_contained, NC * 4, hipMemcpyHostToDevice, s));
+        // candidate -> device pair order (the pairs were sorted on the device)
+        hipLaunchKernelGGL(k_remap_pairs, dim3((nc + 255) / 256), dim3(256), 0, s, m.pair.as<int32_t>(), m.pairc.as<int32_t>(),
+                           my.inv_d.as<int32_t>(), nc);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.seqlen.p, in->cand_seq_len, NC * 4, hipMemcpyHostToDevice, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.seqid.p, in->cand_seq_id, NC * 4, hipMemcpyHostToDevice, s));
     }

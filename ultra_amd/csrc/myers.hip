@@ -1222,36 +1222,6 @@ constexpr int kBuckets = 5;
 inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 10 ? 3 : 4; }
 inline int bucket_wmax(int b) { return b == 0 ? 2 : b < 4 ? 4 : 8; } // words per lane: LDS per wavefront = S * wmax * 512 B
 
-// work items of one pass: for every class the item range [b, e) cut into wavefront-sized pieces
-struct PassRange { int cls; int64_t b, e; const int32_t *t_len; };
-
-void build_work(const std::vector<PassRange> &ranges, std::vector<WorkItem> out[kBuckets])
-{
-    for (int b = 0; b < kBuckets; b++) out[b].clear();
-    // Without target lengths (start pass) the cost of an item is its class's alone and grows with the class: walking the
-    // classes downwards IS heaviest first - no sort on the host while the GPU waits for this list.
-    bool by_class = true;
-    for (const PassRange &r : ranges) by_class = by_class && !r.t_len;
-    for (size_t ri = 0; ri < ranges.size(); ri++) {
-        const PassRange &r = by_class ? ranges[ranges.size() - 1 - ri] : ranges[ri];
-        const int G = kClasses[r.cls].G, W = kClasses[r.cls].W;
-        const int per = 64 / G;
-        const int rows = 64 * G * W;
-        for (int64_t i = r.b; i < r.e; i += per) {
-            WorkItem wi;
-            wi.base = i; wi.end = r.e; wi.cls = r.cls;
-            // cost ~ words per lane x columns; without target lengths (start pass) columns ~ rows
-            const int64_t last = std::min<int64_t>(i + per, r.e) - 1;
-            const int64_t cols = r.t_len ? r.t_len[last] : rows;
-            wi.cost = (int32_t)std::min<int64_t>((int64_t)W * (cols + G), 0x7fffffff);
-            out[bucket_of(r.cls)].push_back(wi);
-        }
-    }
-    if (by_class) return;
-    for (int b = 0; b < kBuckets; b++)
-        std::stable_sort(out[b].begin(), out[b].end(), [](const WorkItem &x, const WorkItem &y) { return x.cost > y.cost; });
-}
-
 template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket, const WorkItem *d_list, int32_t n)
 {
     if (n <= 0) return hipSuccess;
@@ -1314,7 +1284,8 @@ void ultra_myers_free(ultra_ctx *ctx)
     DevBuf *bufs[] = {&st.seq, &st.rseq, &st.qoff, &st.qlen, &st.toff, &st.tlen, &st.k, &st.ed, &st.nloc, &st.slots,
                       &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
                       &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff,
-                      &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp, &st.trace2};
+                      &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp, &st.trace2,
+                      &st.raw, &st.lut, &st.u_qoff, &st.u_qlen, &st.u_toff, &st.u_tlen, &st.u_k, &st.skeys, &st.perm_d, &st.inv_d, &st.stats, &st.worktmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto &bk : st.buckets) {
@@ -1323,6 +1294,219 @@ void ultra_myers_free(ultra_ctx *ctx)
         if (bk.ev1) { (void)hipEventDestroy(bk.ev1); bk.ev1 = nullptr; }
     }
     st.classes.clear();
+}
+
+// ---- staging ---------------------------------------------------------------------------------------------------
+// Everything past the raw copies happens on the device: alphabet compaction (presence mask -> dense codes, the encoded
+// arena and its reverse written by one kernel), the order of the pairs (radix sort by size class and target length, so
+// that the 64 pairs of a wavefront run equally long; stable, i.e. the caller's order inside equal keys) and the
+// forward work lists (one item per wavefront, heaviest first within a register bucket).  The host only sees two
+// small read-backs: the presence mask and the per-class counts.
+namespace {
+
+__global__ void __launch_bounds__(256) k_presence(const uint8_t *raw, int64_t n, uint32_t *mask)
+{
+    __shared__ uint32_t sm[8];
+    if (threadIdx.x < 8) sm[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = raw[i];
+        loc[b >> 5] |= 1u << (b & 31);
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) if (loc[w]) atomicOr(&sm[w], loc[w]);
+    __syncthreads();
+    if (threadIdx.x < 8 && sm[threadIdx.x]) atomicOr(&mask[threadIdx.x], sm[threadIdx.x]);
+}
+
+// seq[at + i] = lut[raw[i]] and the mirror image rseq[N - 1 - (at + i)]
+__global__ void __launch_bounds__(256) k_encode(const uint8_t *raw, int64_t n, const uint8_t *lut, uint8_t *seq, uint8_t *rseq, int64_t at, int64_t N)
+{
+    __shared__ uint8_t sl[256];
+    sl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t c = sl[raw[i]];
+        seq[at + i] = c;
+        rseq[N - 1 - (at + i)] = c;
+    }
+}
+
+// stats: [0..14) pairs per size class, [14..28) forward cells per class, [28..42) longest target per class
+__global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const int32_t *t_len, int32_t n, uint32_t *keys, int32_t *idx,
+                                                   unsigned long long *stats)
+{
+    __shared__ unsigned long long sh[3 * kNumSizeClasses];
+    for (int i = threadIdx.x; i < 3 * kNumSizeClasses; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        const int m = q_len[p], t = t_len[p];
+        const uint32_t c = size_class_of(m);
+        keys[p] = (c << 24) | (uint32_t)(t < 0xFFFFFF ? t : 0xFFFFFF);
+        idx[p] = p;
+        atomicAdd(&sh[c], 1ull);
+        atomicAdd(&sh[kNumSizeClasses + c], (unsigned long long)m * (unsigned long long)t);
+        atomicMax(&sh[2 * kNumSizeClasses + c], (unsigned long long)t);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * kNumSizeClasses; i += blockDim.x) {
+        if (!sh[i]) continue;
+        if (i < 2 * kNumSizeClasses) atomicAdd(&stats[i], sh[i]); else atomicMax(&stats[i], sh[i]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gather_pairs(const int32_t *perm, int32_t n, int64_t shift,
+                                                      const int64_t *uq, const int32_t *uql, const int64_t *ut, const int32_t *utl, const int32_t *uk,
+                                                      int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k, int32_t *inv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = perm[i];
+    q_off[i] = uq[p] + shift; t_off[i] = ut[p] + shift;
+    q_len[i] = uql[p]; t_len[i] = utl[p]; k[i] = uk[p];
+    inv[p] = i;
+}
+
+struct WorkRanges { int32_t n; struct { int32_t cls, G, W, first_item; int64_t pb, pe; } r[4]; };
+__global__ void __launch_bounds__(256) k_work_items(WorkRanges wr, const int32_t *t_len, int32_t n_items, WorkItem *items, uint32_t *keys, int32_t *idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    int r = 0;
+    while (r + 1 < wr.n && i >= wr.r[r + 1].first_item) r++;
+    const int per = 64 / wr.r[r].G;
+    WorkItem wi;
+    wi.base = wr.r[r].pb + (int64_t)(i - wr.r[r].first_item) * per;
+    wi.end = wr.r[r].pe;
+    wi.cls = wr.r[r].cls;
+    const int64_t last = (wi.base + per < wi.end ? wi.base + per : wi.end) - 1;
+    const int64_t cost = (int64_t)wr.r[r].W * ((int64_t)t_len[last] + wr.r[r].G); // ~ words per lane x columns
+    wi.cost = (int32_t)(cost < 0x7fffffff ? cost : 0x7fffffff);
+    items[i] = wi;
+    keys[i] = (uint32_t)wi.cost;
+    idx[i] = i;
+}
+__global__ void __launch_bounds__(256) k_gather_work(const WorkItem *items, const int32_t *order, int32_t n, WorkItem *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = items[order[i]];
+}
+
+} // namespace
+
+// Orders the n_pairs pairs that lie UNSORTED in st.u_* (offsets relative to the arena's first byte) and builds the
+// forward work lists.  The arena (st.seq / st.rseq, st.N, st.S) must have been filled on ctx->stream before.
+int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
+{
+    MyersState &st = ctx->my;
+    hipStream_t s = ctx->stream;
+    st.n_pairs = n_pairs;
+    st.perm.clear(); st.perm_on_host = false;
+    st.classes.clear();
+    st.cells = 0;
+    const size_t np = (size_t)std::max(n_pairs, 1);
+    ULTRA_HIP_CHECK(ctx, st.qoff.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.toff.ensure(np * 8));
+    ULTRA_HIP_CHECK(ctx, st.qlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.tlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.k.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.ed.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.nloc.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.firstins.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.nops.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.hitpairs.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.slots.ensure(np * 4 * (size_t)ctx->cfg.loc_slots));
+    ULTRA_HIP_CHECK(ctx, st.packed.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.scanned.ensure(np * 8));
+    ULTRA_HIP_CHECK(ctx, st.locoff.ensure((np + 1) * 8)); ULTRA_HIP_CHECK(ctx, st.hitoff.ensure((np + 1) * 8));
+    ULTRA_HIP_CHECK(ctx, st.bounds.ensure(64 * 8 * 4));
+    ULTRA_HIP_CHECK(ctx, st.skeys.ensure(np * 4 * 4)); // keys in | keys out | index in | index out (pairs, then work items)
+    ULTRA_HIP_CHECK(ctx, st.perm_d.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.inv_d.ensure(np * 4));
+    ULTRA_HIP_CHECK(ctx, st.stats.ensure(3 * kNumSizeClasses * 8));
+    for (auto &e : st.ev) if (!e) ULTRA_HIP_CHECK(ctx, hipEventCreate(&e));
+    for (int b = 0; b < kBuckets; b++) {
+        MyersBucket &bk = st.buckets[b];
+        bk.n_fwd = 0; bk.wmax = bucket_wmax(b); bk.cells = 0;
+        if (!bk.ev0) { ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev0)); ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev1)); }
+    }
+    if (n_pairs == 0) { ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); st.staged = true; return ULTRA_OK; }
+    ultra_drain_guard drain(ctx);
+    uint32_t *k_in = st.skeys.as<uint32_t>(), *k_out = k_in + np;
+    int32_t *i_in = (int32_t *)(k_out + np), *i_out = i_in + np;
+    const unsigned gp = (unsigned)((n_pairs + 255) / 256);
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.stats.p, 0, 3 * kNumSizeClasses * 8, s));
+    hipLaunchKernelGGL(k_pair_keys, dim3(gp), dim3(256), 0, s, st.u_qlen.as<int32_t>(), st.u_tlen.as<int32_t>(), n_pairs, k_in, i_in,
+                       st.stats.as<unsigned long long>());
+    {
+        size_t tmp_bytes = 0;
+        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 28, s));
+        ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
+        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 28, s));
+    }
+    hipLaunchKernelGGL(k_gather_pairs, dim3(gp), dim3(256), 0, s, st.perm_d.as<int32_t>(), n_pairs, (int64_t)kArenaPad,
+                       st.u_qoff.as<int64_t>(), st.u_qlen.as<int32_t>(), st.u_toff.as<int64_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(),
+                       st.qoff.as<int64_t>(), st.qlen.as<int32_t>(), st.toff.as<int64_t>(), st.tlen.as<int32_t>(), st.k.as<int32_t>(),
+                       st.inv_d.as<int32_t>());
+    ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    unsigned long long h_stats[3 * kNumSizeClasses];
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_stats, st.stats.p, sizeof h_stats, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    int64_t at = 0;
+    for (int c = 0; c < kNumSizeClasses; c++) {
+        const int64_t cnt = (int64_t)h_stats[c];
+        if (cnt <= 0) continue;
+        MyersClass mc; mc.G = kClasses[c].G; mc.W = kClasses[c].W; mc.pb = at; mc.pe = at + cnt;
+        mc.max_t = (int32_t)h_stats[2 * kNumSizeClasses + c];
+        mc.lb = mc.le = mc.hb = mc.he = 0;
+        mc.cells = (double)h_stats[kNumSizeClasses + c];
+        st.classes.push_back(mc);
+        st.cells += mc.cells;
+        st.buckets[bucket_of(c)].cells += mc.cells;
+        at += cnt;
+    }
+    if (at != n_pairs) return ultra_fail(ctx, ULTRA_E_HIP, "ultra_myers_stage: size-class counts do not add up");
+    // forward work lists (heaviest wavefront first), one per register bucket
+    for (int b = 0; b < kBuckets; b++) {
+        MyersBucket &bk = st.buckets[b];
+        WorkRanges wr; wr.n = 0;
+        int32_t n_items = 0;
+        for (auto &mc : st.classes) {
+            const int cls = class_of(64 * mc.G * mc.W);
+            if (bucket_of(cls) != b) continue;
+            const int per = 64 / mc.G;
+            wr.r[wr.n].cls = cls; wr.r[wr.n].G = mc.G; wr.r[wr.n].W = mc.W; wr.r[wr.n].first_item = n_items;
+            wr.r[wr.n].pb = mc.pb; wr.r[wr.n].pe = mc.pe;
+            wr.n++;
+            n_items += (int32_t)((mc.pe - mc.pb + per - 1) / per);
+        }
+        bk.n_fwd = n_items;
+        if (n_items <= 0) continue;
+        ULTRA_HIP_CHECK(ctx, bk.fwd_list.ensure((size_t)n_items * sizeof(WorkItem)));
+        ULTRA_HIP_CHECK(ctx, bk.fwd_flag.ensure((size_t)n_items * sizeof(int32_t)));
+        ULTRA_HIP_CHECK(ctx, st.worktmp.ensure((size_t)n_items * sizeof(WorkItem)));
+        const unsigned gi = (unsigned)((n_items + 255) / 256);
+        hipLaunchKernelGGL(k_work_items, dim3(gi), dim3(256), 0, s, wr, st.tlen.as<int32_t>(), n_items, st.worktmp.as<WorkItem>(), k_in, i_in);
+        size_t tmp_bytes = 0;
+        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)n_items, 0, 32, s));
+        ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
+        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs_desc(st.sorttmp.p, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)n_items, 0, 32, s));
+        hipLaunchKernelGGL(k_gather_work, dim3(gi), dim3(256), 0, s, st.worktmp.as<WorkItem>(), i_out, n_items, bk.fwd_list.as<WorkItem>());
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    drain.dismiss();
+    st.staged = true;
+    return ULTRA_OK;
+}
+
+// caller's pair index of every sorted position, on the host (only the Myers-only entry points need it)
+int ultra_myers_host_perm(ultra_ctx *ctx)
+{
+    MyersState &st = ctx->my;
+    if (st.perm_on_host) return ULTRA_OK;
+    st.perm.resize((size_t)st.n_pairs);
+    if (st.n_pairs > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.perm.data(), st.perm_d.p, (size_t)st.n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    st.perm_on_host = true;
+    return ULTRA_OK;
 }
 
 int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
@@ -1334,109 +1518,64 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
     if (n_pairs < 0 || (n_pairs > 0 && (!arena || !q_off || !q_len || !t_off || !t_len || !k)))
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_stage: null pointer or negative pair count");
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    // validate + classify
-    std::vector<int> cls((size_t)n_pairs);
-    double cells = 0;
+    // the device code trusts the descriptors: validate them here
     for (int32_t p = 0; p < n_pairs; p++) {
         if (q_len[p] < 1 || t_len[p] < 1 || q_off[p] < 0 || t_off[p] < 0 ||
             (uint64_t)q_off[p] + (uint64_t)q_len[p] > arena_len || (uint64_t)t_off[p] + (uint64_t)t_len[p] > arena_len)
             return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_stage: pair " + std::to_string(p) +
                                                     " has an empty sequence or offsets outside the arena");
-        int c = class_of(q_len[p]);
-        if (c < 0)
+        if (class_of(q_len[p]) < 0)
             return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: query of pair " + std::to_string(p) + " is longer than " +
                                                             std::to_string(kMaxQuery) + " bases");
-        cls[p] = c;
-        cells += (double)q_len[p] * (double)t_len[p];
     }
-    // alphabet compaction: distinct bytes -> dense codes (comparisons stay byte-exact)
-    int code_of[256];
-    for (int i = 0; i < 256; i++) code_of[i] = -1;
-    std::vector<uint8_t> enc(arena_len + 2 * kArenaPad, 0);
-    int S = 0;
-    {
-        bool seen[256] = {false};
-        for (size_t i = 0; i < arena_len; i++) seen[arena[i]] = true;
-        for (int i = 0; i < 256; i++) if (seen[i]) code_of[i] = S++;
-        if (S > kMaxSymbols)
-            return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: more than 16 distinct symbols in the batch");
-        if (S == 0) S = 1;
-        for (size_t i = 0; i < arena_len; i++) enc[kArenaPad + i] = (uint8_t)code_of[arena[i]];
-    }
-    // order pairs by (class, target length) so that a wavefront's lanes run equally long
-    st.perm.resize((size_t)n_pairs);
-    for (int32_t p = 0; p < n_pairs; p++) st.perm[p] = p;
-    std::stable_sort(st.perm.begin(), st.perm.end(), [&](int32_t a, int32_t b) {
-        if (cls[a] != cls[b]) return cls[a] < cls[b];
-        return t_len[a] < t_len[b];
-    });
-    st.classes.clear();
-    st.h_qoff.resize(n_pairs); st.h_toff.resize(n_pairs); st.h_qlen.resize(n_pairs); st.h_tlen.resize(n_pairs); st.h_k.resize(n_pairs);
-    for (int32_t i = 0; i < n_pairs; i++) {
-        int32_t p = st.perm[i];
-        st.h_qoff[i] = q_off[p] + (int64_t)kArenaPad; st.h_toff[i] = t_off[p] + (int64_t)kArenaPad;
-        st.h_qlen[i] = q_len[p]; st.h_tlen[i] = t_len[p]; st.h_k[i] = k[p];
-        int c = cls[p];
-        if (st.classes.empty() || st.classes.back().G != kClasses[c].G || st.classes.back().W != kClasses[c].W) {
-            MyersClass mc; mc.G = kClasses[c].G; mc.W = kClasses[c].W; mc.pb = i; mc.pe = i; mc.max_t = 0;
-            mc.lb = mc.le = mc.hb = mc.he = 0;
-            mc.cells = 0;
-            st.classes.push_back(mc);
-        }
-        st.classes.back().pe = i + 1;
-        st.classes.back().cells += (double)q_len[p] * (double)t_len[p];
-        st.classes.back().max_t = std::max(st.classes.back().max_t, t_len[p]);
-    }
-    st.n_pairs = n_pairs; st.N = (int64_t)enc.size(); st.S = S; st.cells = cells;
-    const size_t np = (size_t)std::max(n_pairs, 1);
-    ULTRA_HIP_CHECK(ctx, st.seq.ensure(enc.size() + 16));
-    ULTRA_HIP_CHECK(ctx, st.rseq.ensure(enc.size() + 16));
-    ULTRA_HIP_CHECK(ctx, st.qoff.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.toff.ensure(np * 8));
-    ULTRA_HIP_CHECK(ctx, st.qlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.tlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.k.ensure(np * 4));
-    ULTRA_HIP_CHECK(ctx, st.ed.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.nloc.ensure(np * 4));
-    ULTRA_HIP_CHECK(ctx, st.firstins.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.nops.ensure(np * 4));
-    ULTRA_HIP_CHECK(ctx, st.hitpairs.ensure(np * 4));
-    ULTRA_HIP_CHECK(ctx, st.slots.ensure(np * 4 * (size_t)ctx->cfg.loc_slots));
-    ULTRA_HIP_CHECK(ctx, st.packed.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.scanned.ensure(np * 8));
-    ULTRA_HIP_CHECK(ctx, st.locoff.ensure((np + 1) * 8)); ULTRA_HIP_CHECK(ctx, st.hitoff.ensure((np + 1) * 8));
-    ULTRA_HIP_CHECK(ctx, st.bounds.ensure(64 * 8 * 4));
     hipStream_t s = ctx->stream;
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.seq.p, enc.data(), enc.size(), hipMemcpyHostToDevice, s));
-    if (n_pairs > 0) {
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.qoff.p, st.h_qoff.data(), np * 8, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.toff.p, st.h_toff.data(), np * 8, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.qlen.p, st.h_qlen.data(), np * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.tlen.p, st.h_tlen.data(), np * 4, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.k.p, st.h_k.data(), np * 4, hipMemcpyHostToDevice, s));
-    }
-    {
-        int64_t n = st.N;
-        hipLaunchKernelGGL(k_reverse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st.seq.as<uint8_t>(), st.rseq.as<uint8_t>(), n);
-        ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    }
-    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // enc/h_* are host temporaries
-    for (auto &e : st.ev) if (!e) ULTRA_HIP_CHECK(ctx, hipEventCreate(&e));
-    {
-        // forward work lists (heaviest wavefront first), one per register bucket
-        std::vector<PassRange> ranges;
-        for (auto &mc : st.classes) ranges.push_back(PassRange{class_of(64 * mc.G * mc.W), mc.pb, mc.pe, st.h_tlen.data()});
-        build_work(ranges, st.h_work);
-        for (int b = 0; b < kBuckets; b++) {
-            MyersBucket &bk = st.buckets[b];
-            bk.n_fwd = (int32_t)st.h_work[b].size();
-            bk.wmax = bucket_wmax(b);
-            bk.cells = 0;
-            for (auto &mc : st.classes) if (bucket_of(class_of(64 * mc.G * mc.W)) == b) bk.cells += mc.cells;
-            if (!bk.ev0) { ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev0)); ULTRA_HIP_CHECK(ctx, hipEventCreate(&bk.ev1)); }
-            if (bk.n_fwd <= 0) continue;
-            ULTRA_HIP_CHECK(ctx, bk.fwd_list.ensure(st.h_work[b].size() * sizeof(WorkItem)));
-            ULTRA_HIP_CHECK(ctx, bk.fwd_flag.ensure(st.h_work[b].size() * sizeof(int32_t)));
-            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(bk.fwd_list.p, st.h_work[b].data(), st.h_work[b].size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
-        }
+    ultra_drain_guard drain(ctx);
+    // ---- arena: raw bytes up, alphabet compaction (distinct bytes -> dense codes, comparisons stay byte-exact) ----
+    const int64_t N = (int64_t)arena_len + 2 * (int64_t)kArenaPad;
+    ULTRA_HIP_CHECK(ctx, st.raw.ensure(arena_len + 16));
+    ULTRA_HIP_CHECK(ctx, st.seq.ensure((size_t)N + 16)); ULTRA_HIP_CHECK(ctx, st.rseq.ensure((size_t)N + 16));
+    ULTRA_HIP_CHECK(ctx, st.lut.ensure(256 + 32));
+    uint32_t *d_mask = (uint32_t *)(st.lut.as<uint8_t>() + 256);
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_mask, 0, 32, s));
+    uint32_t h_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (arena_len > 0 && n_pairs > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.raw.p, arena, arena_len, hipMemcpyHostToDevice, s));
+        const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)arena_len + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_presence, dim3(gb), dim3(256), 0, s, st.raw.as<uint8_t>(), (int64_t)arena_len, d_mask);
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, d_mask, 32, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
     }
-    st.staged = true;
-    return ULTRA_OK;
+    uint8_t h_lut[256];
+    int S = 0;
+    for (int i = 0; i < 256; i++) { h_lut[i] = 0; if (h_mask[i >> 5] >> (i & 31) & 1u) h_lut[i] = (uint8_t)(S < 255 ? S : 255), S++; }
+    if (S > kMaxSymbols)
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: more than 16 distinct symbols in the batch");
+    if (S == 0) S = 1;
+    st.N = N; st.S = S;
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.seq.p, 0, kArenaPad, s));
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.seq.as<uint8_t>() + kArenaPad + arena_len, 0, kArenaPad + 16, s));
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.rseq.p, 0, kArenaPad, s));
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.rseq.as<uint8_t>() + kArenaPad + arena_len, 0, kArenaPad + 16, s));
+    if (arena_len > 0 && n_pairs > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.lut.p, h_lut, 256, hipMemcpyHostToDevice, s));
+        const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)arena_len + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_encode, dim3(gb), dim3(256), 0, s, st.raw.as<uint8_t>(), (int64_t)arena_len, st.lut.as<uint8_t>(),
+                           st.seq.as<uint8_t>(), st.rseq.as<uint8_t>(), (int64_t)kArenaPad, N);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    // ---- pair descriptors up, as they are ----
+    const size_t np = (size_t)std::max(n_pairs, 1);
+    ULTRA_HIP_CHECK(ctx, st.u_qoff.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.u_toff.ensure(np * 8));
+    ULTRA_HIP_CHECK(ctx, st.u_qlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.u_tlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.u_k.ensure(np * 4));
+    if (n_pairs > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.u_qoff.p, q_off, np * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.u_toff.p, t_off, np * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.u_qlen.p, q_len, np * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.u_tlen.p, t_len, np * 4, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.u_k.p, k, np * 4, hipMemcpyHostToDevice, s));
+    }
+    drain.dismiss();
+    return ultra_myers_stage_pairs(ctx, n_pairs);
 }
 
 int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)

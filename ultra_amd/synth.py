@@ -23,10 +23,23 @@ import numpy as np
 Mem = namedtuple('Mem', ['x', 'y', 'c', 'd', 'val', 'j', "exon_part_id"])
 
 PRESETS = {
-    # name: (error rate, read length mean, sd, min, lognormal tail?, min_acc)
+    # read models of the BASELINE.json configs.  The Python simulator below draws
+    # lengths from N(len_mean, len_sd); the native simulator (make_reads_native) also knows the log-normal model
+    # of C5: median len_median, sigma len_sigma, clipped to [len_min, len_max], 3'-biased truncation.
     "isoseq": dict(err=0.01, len_mean=2500, len_sd=800, len_min=300, min_acc=0.8),
     "ont_cdna": dict(err=0.07, len_mean=1000, len_sd=400, len_min=200, min_acc=0.6),
-    "ont_drna": dict(err=0.12, len_mean=1100, len_sd=900, len_min=200, min_acc=0.6),
+    "ont_drna": dict(err=0.12, len_mean=1100, len_sd=900, len_min=200, min_acc=0.6,
+                     len_median=1100, len_sigma=0.75, len_max=15000, bias3p=0.7),
+}
+
+# annotation shapes: "small" = the toy annotation of the parity tests; "c3" = SURVEY.md section 8d C3, GRCh38 /
+# GENCODE-like: ~60 k genes on 24 chromosomes, merged exon parts per gene (alternative splice sites cut a part
+# into 2-3 segments), a share of overlapping genes that share exon parts (a hit on a shared segment pulls in the
+# small segments of every gene it belongs to, classify_read_with_mams.py:264-271).
+WORLDS = {
+    "small": dict(n_genes=1500, n_chr=8),
+    "c2": dict(n_genes=900, n_chr=1, exon_mean=12.0, max_exons=60, split_frac=0.45, overlap_frac=0.15),
+    "c3": dict(n_genes=60000, n_chr=24, exon_mean=12.0, max_exons=60, split_frac=0.45, overlap_frac=0.15),
 }
 
 
@@ -51,21 +64,34 @@ class World:
                 self.segment_to_gene, self.gene_to_small_segments)
 
 
+_ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
 def _rand_seq(rng, n):
-    return "".join("ACGT"[i] for i in rng.randint(0, 4, size=n))
+    return _ACGT[rng.randint(0, 4, size=n)].tobytes().decode()
 
 
 def make_world(seed=20241008, n_genes=200, n_chr=2, flank=1000, small_thr=200, max_exons=30,
-               small_exon_frac=0.03, split_frac=0.3):
+               small_exon_frac=0.03, split_frac=0.3, exon_mean=9.0, overlap_frac=0.0):
+    """overlap_frac: share of genes that overlap the previous gene of their chromosome - they reuse a run of its
+    exon parts (same coordinates, so the shared segments belong to both genes) and add exons of their own behind it."""
     rng = np.random.RandomState(seed)
     w = World()
     pos = [5000] * n_chr
+    last_gene = [None] * n_chr      # (exons, cuts per exon) of the previous gene on each chromosome
     for g in range(n_genes):
         chr_id = g % n_chr
         gene_id = "gene%05d" % g
-        n_ex = int(min(max_exons, max(1, rng.geometric(1.0 / 9.0))))
-        p = pos[chr_id] + 2 * flank + int(rng.randint(0, 3000))
-        gene_start = p
+        n_ex = int(min(max_exons, max(1, rng.geometric(1.0 / exon_mean))))
+        shared = []
+        if overlap_frac > 0.0 and last_gene[chr_id] is not None and rng.rand() < overlap_frac:
+            prev = last_gene[chr_id]
+            k = int(rng.randint(1, len(prev) + 1))
+            a0 = int(rng.randint(0, len(prev) - k + 1))
+            shared = prev[a0:a0 + k]
+            p = pos[chr_id] - 2 * flank + int(rng.randint(70, 3000))   # own exons follow the previous gene's last one
+        else:
+            p = pos[chr_id] + 2 * flank + int(rng.randint(0, 3000))
         exons = []
         for e in range(n_ex):
             if rng.rand() < small_exon_frac:
@@ -74,9 +100,17 @@ def make_world(seed=20241008, n_genes=200, n_chr=2, flank=1000, small_thr=200, m
                 ln = int(max(5, min(6000, rng.lognormal(np.log(130.0), 0.9))))
             exons.append((p, p + ln))
             p += ln + int(max(70, min(200000, rng.lognormal(np.log(1500.0), 1.2))))
+        gene_start = shared[0][0] if shared else exons[0][0]
         gene_stop = exons[-1][1]
         pos[chr_id] = gene_stop + 2 * flank
         small = array('L')
+        for (a, b) in shared:         # parts that exist already: this gene joins their segments
+            flat = w.parts_to_segments[key_of(chr_id, a, b)]
+            for i in range(0, len(flat), 3):
+                sk = key_of(flat[i], flat[i + 1], flat[i + 2])
+                w.segment_to_gene[sk].add(gene_id)
+                if flat[i + 2] - flat[i + 1] <= small_thr:
+                    small.extend([flat[i], flat[i + 1], flat[i + 2]])
         for (a, b) in exons:
             seq = _rand_seq(rng, b - a)
             w.part_seq[(chr_id, a, b)] = seq
@@ -97,9 +131,14 @@ def make_world(seed=20241008, n_genes=200, n_chr=2, flank=1000, small_thr=200, m
                     small.extend([chr_id, s0, s1])
             w.parts_to_segments[key_of(chr_id, a, b)] = flat
         w.gene_to_small_segments[gene_id] = small
+        exons = list(shared) + exons
+        n_ex = len(exons)
+        last_gene[chr_id] = exons
         up = (chr_id, max(0, gene_start - flank), gene_start - 1)
         down = (chr_id, gene_stop, gene_stop + flank)
         for f in (up, down):
+            if f in w.part_seq:       # an overlapping gene that starts on the previous gene's first exon
+                continue
             fs = _rand_seq(rng, f[2] - f[1])
             w.part_seq[f] = fs
             w.ref_flank_sequences[key_of(*f)] = fs
@@ -208,3 +247,137 @@ def simulate_instance(w, rng, preset="ont_cdna", min_nam=15, flank_start_prob=0.
 def make_instances(w, n, seed=1, preset="ont_cdna", **kw):
     rng = np.random.RandomState(seed)
     return [simulate_instance(w, rng, preset, **kw) for _ in range(n)]
+
+
+# ---- native read simulator (csrc/synth.cpp -> libultra_synth.so): the same model at a million reads ---------------
+import ctypes as _C
+import os as _os
+
+_SYNTH_LIB = None
+
+
+class _SynthWorld(_C.Structure):
+    _fields_ = [("n_tr", _C.c_int64), ("tr_off", _C.c_void_p), ("tr_piece", _C.c_void_p), ("tr_up", _C.c_void_p),
+                ("tr_down", _C.c_void_p), ("piece_chr", _C.c_void_p), ("piece_start", _C.c_void_p),
+                ("piece_stop", _C.c_void_p), ("piece_seq", _C.c_void_p), ("pool", _C.c_void_p)]
+
+
+class _SynthParams(_C.Structure):
+    _fields_ = [("seed", _C.c_uint64), ("n_reads", _C.c_int64), ("err", _C.c_double), ("len_model", _C.c_int32),
+                ("len_a", _C.c_double), ("len_b", _C.c_double), ("len_min", _C.c_int32), ("len_max", _C.c_int32),
+                ("bias3p", _C.c_double), ("flank_start_prob", _C.c_double), ("flank_end_prob", _C.c_double),
+                ("min_nam", _C.c_int32), ("n_threads", _C.c_int32)]
+
+
+def _synth_lib():
+    global _SYNTH_LIB
+    if _SYNTH_LIB is None:
+        path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libultra_synth.so")
+        if not _os.path.exists(path):
+            raise OSError("libultra_synth.so not found - build it with `make -C ultra_amd/csrc`")
+        lib = _C.CDLL(path)
+        lib.synth_generate.restype = _C.c_void_p
+        lib.synth_generate.argtypes = [_C.POINTER(_SynthWorld), _C.POINTER(_SynthParams)]
+        lib.synth_sizes.argtypes = [_C.c_void_p] + [_C.POINTER(_C.c_int64)] * 3
+        lib.synth_sizes.restype = None
+        lib.synth_copy.argtypes = [_C.c_void_p] + [_C.c_void_p] * 9
+        lib.synth_copy.restype = None
+        lib.synth_free.argtypes = [_C.c_void_p]
+        lib.synth_free.restype = None
+        _SYNTH_LIB = lib
+    return _SYNTH_LIB
+
+
+class FlatWorld(object):
+    """Transcripts and part sequences of a World as flat arrays (what the native simulator reads)."""
+
+    def __init__(self, w):
+        ids, chunks, size = {}, [], 0
+        chrs, starts, stops, seqoff = [], [], [], []
+        for part, seq in w.part_seq.items():
+            ids[part] = len(chrs)
+            chrs.append(part[0]); starts.append(part[1]); stops.append(part[2]); seqoff.append(size)
+            b = seq.encode()
+            chunks.append(b); size += len(b)
+        tr_off, tr_piece, tr_up, tr_down = [0], [], [], []
+        for chr_id, _, exons, up, down in w.transcripts:
+            tr_piece.extend(ids[(chr_id, a, b)] for a, b in exons)
+            tr_off.append(len(tr_piece)); tr_up.append(ids[up]); tr_down.append(ids[down])
+        a64 = lambda v: np.ascontiguousarray(v, np.int64)
+        self.tr_off, self.tr_piece, self.tr_up, self.tr_down = a64(tr_off), a64(tr_piece), a64(tr_up), a64(tr_down)
+        self.piece_chr, self.piece_start, self.piece_stop, self.piece_seq = a64(chrs), a64(starts), a64(stops), a64(seqoff)
+        self.pool = np.frombuffer(b"".join(chunks) or b"\0", np.uint8)
+        self.n_tr = len(w.transcripts)
+
+    def c_struct(self):
+        ptr = lambda a: a.ctypes.data_as(_C.c_void_p)
+        return _SynthWorld(self.n_tr, ptr(self.tr_off), ptr(self.tr_piece), ptr(self.tr_up), ptr(self.tr_down), ptr(self.piece_chr),
+                           ptr(self.piece_start), ptr(self.piece_stop), ptr(self.piece_seq), ptr(self.pool))
+
+
+class ReadSet(object):
+    """n reads with their NAM chains as flat arrays: exactly the fields of ultra_plan_request (include/ultra_hip.h)
+    plus the read coordinates c, d of every NAM and the chromosome of every read."""
+    __slots__ = ("reads", "read_off", "nam_off", "nam_part", "nam_x", "nam_y", "nam_c", "nam_d", "chr")
+
+    def __len__(self):
+        return len(self.read_off) - 1
+
+    def slice(self, a, b):
+        """Reads [a, b) as a ReadSet of their own (offsets rebased; arrays are views where possible)."""
+        r = ReadSet()
+        r0, r1, n0, n1 = int(self.read_off[a]), int(self.read_off[b]), int(self.nam_off[a]), int(self.nam_off[b])
+        r.reads = self.reads[r0:r1]
+        r.read_off = self.read_off[a:b + 1] - r0
+        r.nam_off = self.nam_off[a:b + 1] - n0
+        r.nam_part = self.nam_part[3 * n0:3 * n1]
+        r.nam_x, r.nam_y, r.nam_c, r.nam_d = self.nam_x[n0:n1], self.nam_y[n0:n1], self.nam_c[n0:n1], self.nam_d[n0:n1]
+        r.chr = self.chr[a:b]
+        return r
+
+    def instance(self, i):
+        """(read_seq, solution, chr_id) of read i in the form simulate_instance returns (for the oracle)."""
+        r0, r1, n0, n1 = int(self.read_off[i]), int(self.read_off[i + 1]), int(self.nam_off[i]), int(self.nam_off[i + 1])
+        sol = []
+        for j, u in enumerate(range(n0, n1)):
+            pid = "{0}^{1}^{2}".format(int(self.nam_part[3 * u]), int(self.nam_part[3 * u + 1]), int(self.nam_part[3 * u + 2]))
+            x, y, c, d = int(self.nam_x[u]), int(self.nam_y[u]), int(self.nam_c[u]), int(self.nam_d[u])
+            sol.append(Mem(x, y, c, d, y - x + 1, j, pid))
+        return self.reads[r0:r1].tobytes().decode(), sol, int(self.chr[i])
+
+
+def make_reads_native(flat, n, seed=1, preset="ont_cdna", min_nam=15, flank_start_prob=0.15, flank_end_prob=0.1, threads=0):
+    """n simulated reads + NAM chains as a ReadSet, generated by libultra_synth.so (deterministic in seed and n; a
+    different random stream than make_instances).  flat: FlatWorld."""
+    P = PRESETS[preset]
+    lib = _synth_lib()
+    prm = _SynthParams()
+    prm.seed, prm.n_reads, prm.err = int(seed), int(n), float(P["err"])
+    if "len_median" in P:
+        prm.len_model, prm.len_a, prm.len_b = 1, float(P["len_median"]), float(P["len_sigma"])
+        prm.len_max, prm.bias3p = int(P["len_max"]), float(P["bias3p"])
+    else:
+        prm.len_model, prm.len_a, prm.len_b, prm.len_max, prm.bias3p = 0, float(P["len_mean"]), float(P["len_sd"]), 0, 0.0
+    prm.len_min = int(P["len_min"])
+    prm.flank_start_prob, prm.flank_end_prob, prm.min_nam = float(flank_start_prob), float(flank_end_prob), int(min_nam)
+    prm.n_threads = int(threads) if threads else max(1, min(16, len(_os.sched_getaffinity(0))))
+    cw = flat.c_struct()
+    h = lib.synth_generate(_C.byref(cw), _C.byref(prm))
+    if not h:
+        raise RuntimeError("synth_generate failed")
+    try:
+        nr, nb, nn = _C.c_int64(), _C.c_int64(), _C.c_int64()
+        lib.synth_sizes(h, _C.byref(nr), _C.byref(nb), _C.byref(nn))
+        rs = ReadSet()
+        rs.reads = np.empty(max(nb.value, 1), np.uint8)
+        rs.read_off = np.empty(nr.value + 1, np.int64); rs.nam_off = np.empty(nr.value + 1, np.int64)
+        rs.nam_part = np.empty(3 * nn.value, np.int64)
+        rs.nam_x, rs.nam_y = np.empty(nn.value, np.int64), np.empty(nn.value, np.int64)
+        rs.nam_c, rs.nam_d = np.empty(nn.value, np.int64), np.empty(nn.value, np.int64)
+        rs.chr = np.empty(nr.value, np.int32)
+        lib.synth_copy(h, *[a.ctypes.data_as(_C.c_void_p) for a in (rs.reads, rs.read_off, rs.nam_off, rs.nam_part, rs.nam_x,
+                                                                  rs.nam_y, rs.nam_c, rs.nam_d, rs.chr)])
+        rs.reads = rs.reads[:nb.value]
+    finally:
+        lib.synth_free(h)
+    return rs
