@@ -216,6 +216,8 @@ typedef struct ultra_mam_input {
     const int64_t *inst_cand_off;       /* [n_inst + 1] */
     const int32_t *inst_read_len;
     const int64_t *inst_first_part_stop, *inst_last_part_start;
+    const int32_t *cand_chr;            /* optional (may be NULL): chromosome id of every candidate's MAMs (ref_chr_id of
+                                           :17); only needed when ultra_mam_fetch is asked for chain_chr */
 } ultra_mam_input;
 
 /*
@@ -231,6 +233,10 @@ typedef struct ultra_mam_output {
     int32_t *chain_x, *chain_y, *chain_c, *chain_d; double *chain_val; int32_t *chain_msl, *chain_cand, *chain_j;
     int64_t mam_cap; int64_t *mam_off;
     int32_t *mam_x, *mam_y, *mam_c, *mam_d; double *mam_val; int32_t *mam_msl, *mam_cand;
+    /* optional (may be NULL), per chain element like chain_x: the candidate kind (0..5, the label of its mam_id) and
+     * the chromosome id of the MAM (ref_chr_id) - with chain_x / chain_y (= the candidate's e_start / e_stop) this is
+     * everything a host needs to rebuild the reference's mam tuples without the candidate arrays */
+    uint8_t *chain_kind; int32_t *chain_chr;
 } ultra_mam_output;
 
 int ultra_mam_batch(ultra_ctx *ctx, const ultra_mam_input *in, double min_acc, ultra_mam_output *out);
@@ -294,6 +300,31 @@ const ultra_mam_input *ultra_plan_input(const ultra_plan *plan);
 int ultra_plan_cands(const ultra_plan *plan, const int32_t **chr, const int32_t **ident_chr, double *cells);
 void ultra_plan_destroy(ultra_plan *plan);
 const char *ultra_plan_last_error(void);
+
+/*
+ * The same enumeration ON THE DEVICE.  ultra_dindex_create flattens the host index once more and uploads it (segment
+ * records in (start, stop, chromosome) order, one hash table for parts and flanks, the raw sequence pool: a few
+ * hundred MB for a human annotation, resident in HBM).  ultra_mam_stage_nams then takes the place of
+ * ultra_plan_create + ultra_mam_stage for a batch: the NAM chains and the reads go up, candidates and (query, target,
+ * k) pairs are produced in device memory - over the resident pool, no per-batch copy of segment sequences - and the
+ * context is left staged for ultra_mam_run / ultra_mam_fetch.  Results are identical to the host-planned batch.
+ * Requirements beyond ultra_plan_create's: coordinates < 2^31, a part's segments on the part's chromosome, at most
+ * 2048 raw hits / list entries, 64 genes and 16 flanks per instance (ULTRA_E_UNSUPPORTED otherwise: plan that batch
+ * on the host).  ultra_mam_fetch's chain_cand then indexes candidate arrays that only exist on the device: ask for
+ * chain_kind / chain_chr instead.
+ */
+typedef struct ultra_dindex ultra_dindex;
+int ultra_dindex_create(int device, const ultra_index *idx, ultra_dindex **out);
+void ultra_dindex_destroy(ultra_dindex *dix);
+const char *ultra_dindex_last_error(void);
+int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dix, const ultra_plan_request *rq);
+/* device copies of the staged batch's candidate arrays, for tests that compare the two planners: any pointer may be
+ * NULL; capacities are the counts ultra_mam_counts reports */
+int ultra_mam_counts(const ultra_ctx *ctx, int32_t *n_inst, int32_t *n_cand, int32_t *n_pairs);
+int ultra_mam_fetch_plan(ultra_ctx *ctx, int64_t *inst_cand_off, int32_t *inst_read_len, int64_t *inst_fps, int64_t *inst_lps,
+                         uint8_t *cand_kind, int32_t *cand_e_start, int32_t *cand_e_stop, int32_t *cand_pair, int32_t *cand_pair_contained,
+                         int32_t *cand_seq_len, int32_t *cand_seq_id, int32_t *cand_chr,
+                         int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k);
 
 #ifdef __cplusplus
 }

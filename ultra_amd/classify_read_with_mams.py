@@ -309,6 +309,52 @@ def results_to_python(batch, res):
     return out
 
 
+_SEG_NAMES = {}
+
+
+def mam_name(kind, chr_id, e_start, e_stop):
+    """mam_id of a chain element from what a want_names fetch returns: str(segm_id) + label for segments
+    (segm_id = array('L', [chr, start, stop]).tobytes(), :445), "flank_<start>_<stop>" + label for flanks (:456)."""
+    key = (kind, chr_id, e_start, e_stop)
+    name = _SEG_NAMES.get(key)
+    if name is None:
+        if len(_SEG_NAMES) > 2000000:
+            _SEG_NAMES.clear()
+        if kind in (1, 4, 5):
+            name = "flank_{0}_{1}".format(e_start, e_stop) + LABELS[kind]
+        else:
+            name = str(array('L', [chr_id, e_start, e_stop]).tobytes()) + LABELS[kind]
+        _SEG_NAMES[key] = name
+    return name
+
+
+def results_from_names(res, read_lens):
+    """(non_covered_regions, value, mam_solution) per instance of a device-planned batch, from a want_names fetch
+    (the candidate arrays never left the GPU)."""
+    out = []
+    n_mam, chain_off, value = res["n_mam"].tolist(), res["chain_off"].tolist(), res["value"].tolist()
+    cx, cy, cc, cd = res["chain_x"].tolist(), res["chain_y"].tolist(), res["chain_c"].tolist(), res["chain_d"].tolist()
+    cval, cmsl, cj = res["chain_val"].tolist(), res["chain_msl"].tolist(), res["chain_j"].tolist()
+    ck, cchr = res["chain_kind"].tolist(), res["chain_chr"].tolist()
+    for i in range(len(n_mam)):
+        if n_mam[i] == 0:
+            out.append(([], -1, tuple()))
+            continue
+        picked = []
+        for r in range(chain_off[i], chain_off[i + 1]):
+            msl = cmsl[r]
+            val = int(cval[r]) if msl == 0 else cval[r]  # 5-8 bp exact segment: the reference stores the int len(exon_seq) (:357-367)
+            picked.append(mam(cx[r], cy[r], cc[r], cd[r], val, cj[r], msl, mam_name(ck[r], cchr[r], cx[r], cy[r]), cchr[r]))
+        gaps = []
+        if picked:
+            gaps.append(picked[0].c)
+            for p, q in zip(picked[:-1], picked[1:]):
+                gaps.append(q.c - p.d - 1)
+            gaps.append(read_lens[i] - picked[-1].d)
+        out.append((gaps, value[i], tuple(picked)))
+    return out
+
+
 def mam_lists_to_python(batch, res):
     """Every instance's complete MAM list (sorted by y, j = position), from a want_all fetch."""
     coff = batch.packed["inst_cand_off"]

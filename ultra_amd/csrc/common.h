@@ -74,6 +74,12 @@ struct MyersState {
     // staging: raw bytes, byte -> code table (+ presence mask), the pairs as the caller ordered them, sort scratch,
     // sorted position -> caller's index and its inverse, per-class statistics, unsorted work items
     DevBuf raw, lut, u_qoff, u_qlen, u_toff, u_tlen, u_k, skeys, perm_d, inv_d, stats, worktmp;
+    // resident-pool mode (ultra_mam_stage_nams): arena = [pad | index pool | reads of the batch (reads_cap) | pad]; the pool
+    // part is encoded once per (context, device index); byte -> code assignments only ever grow
+    uint64_t pool_serial = 0;
+    int64_t reads_cap = 0;
+    uint8_t h_lut[256] = {};
+    bool h_seen[256] = {};
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -94,6 +100,10 @@ struct MamState {
     int64_t *pinned_base = nullptr;  // pinned copy of instbase (first MAM slot of every instance, then the total), read
     size_t pinned_cap = 0;           // back while the Myers passes still run; entries
     std::vector<int32_t> h_slots;    // slots per instance = upper bound of its MAM count
+    bool has_chr = false;            // chr[] holds the chromosome id of every candidate (needed for chain_chr in the fetch)
+    DevBuf chr, ckind, cchr;
+    // device planner (dplan.hip): the request on the device, per-instance counts, overflow list, counters, scan scratch
+    DevBuf d_namoff, d_readoff, d_nampart, d_namx, d_namy, p_ncand, p_npair, p_over, p_misc, p_wide, p_poff;
     DevBuf kind, estart, estop, pair, pairc, seqlen, seqid, candoff, readlen, fps, lps, cap, capoff, instbase, scantmp, flag,
         mx, my, mc, md, mmsl, mcand, mval, nmam, chainidx, chainlen, value, lenw, chainoff, cx, cy, cc, cd, cmsl, ccand, cj, cval;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -104,6 +114,9 @@ struct MamState {
 // queue and serialise, so the default lane count follows that variable (ultra_ctx_create).
 constexpr int kAuxStreams = 7;
 constexpr int kLanes = kAuxStreams + 1;
+
+constexpr int kMaxSymbols = 16;
+constexpr size_t kArenaPad = 64;
 
 struct ultra_ctx {
     int device = 0;
@@ -186,6 +199,10 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
                            const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                            const int32_t *k);
 int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs);
+// presence mask (8 x u32, accumulated with atomicOr) of n raw bytes; seq[at + i] = lut[raw[i]] with the mirror image in rseq
+void ultra_launch_presence(hipStream_t s, const uint8_t *raw, int64_t n, uint32_t *mask);
+void ultra_launch_encode(hipStream_t s, const uint8_t *raw, int64_t n, const uint8_t *lut, uint8_t *seq, uint8_t *rseq, int64_t at, int64_t N);
+void ultra_mam_remap_pairs(ultra_ctx *ctx, int32_t n_cand);
 int ultra_myers_host_perm(ultra_ctx *ctx);
 int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops);
 // caller-provided device workspace of ultra_chain_launch (instead of the context's growable buffers)

@@ -336,6 +336,8 @@ struct GatherArgs {
     int32_t *cx, *cy, *cc, *cd, *cmsl, *ccand, *cj;
     double *cval;
     int32_t n_inst;
+    const uint8_t *kind; const int32_t *chr; // per candidate; chr may be null
+    uint8_t *ckind; int32_t *cchr;
 };
 __global__ void __launch_bounds__(256) k_chain_gather(GatherArgs a)
 {
@@ -349,7 +351,10 @@ __global__ void __launch_bounds__(256) k_chain_gather(GatherArgs a)
         const int64_t r = b + j;
         a.cj[o + t] = j;
         a.cx[o + t] = a.mx[r]; a.cy[o + t] = a.my[r]; a.cc[o + t] = a.mc[r]; a.cd[o + t] = a.md[r];
-        a.cval[o + t] = a.mval[r]; a.cmsl[o + t] = a.mmsl[r]; a.ccand[o + t] = a.mcand[r];
+        const int cand = a.mcand[r];
+        a.cval[o + t] = a.mval[r]; a.cmsl[o + t] = a.mmsl[r]; a.ccand[o + t] = cand;
+        a.ckind[o + t] = a.kind[cand];
+        a.cchr[o + t] = a.chr ? a.chr[cand] : -1;
     }
 }
 
@@ -361,10 +366,19 @@ void ultra_mam_free(ultra_ctx *ctx)
     DevBuf *bufs[] = {&m.kind, &m.estart, &m.estop, &m.pair, &m.pairc, &m.seqlen, &m.seqid, &m.candoff, &m.readlen, &m.fps, &m.lps,
                       &m.cap, &m.capoff, &m.instbase, &m.scantmp, &m.flag, &m.mx, &m.my, &m.mc, &m.md, &m.mmsl, &m.mcand, &m.mval,
                       &m.nmam, &m.chainidx, &m.chainlen, &m.value, &m.lenw, &m.chainoff, &m.cx, &m.cy, &m.cc, &m.cd, &m.cmsl,
-                      &m.ccand, &m.cj, &m.cval};
+                      &m.ccand, &m.cj, &m.cval, &m.chr, &m.ckind, &m.cchr, &m.d_namoff, &m.d_readoff, &m.d_nampart, &m.d_namx, &m.d_namy,
+                      &m.p_ncand, &m.p_npair, &m.p_over, &m.p_misc, &m.p_wide, &m.p_poff};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : m.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (m.pinned_base) { (void)hipHostFree(m.pinned_base); m.pinned_base = nullptr; m.pinned_cap = 0; }
+}
+
+void ultra_mam_remap_pairs(ultra_ctx *ctx, int32_t nc)
+{
+    if (nc <= 0) return;
+    MamState &m = ctx->mam;
+    hipLaunchKernelGGL(k_remap_pairs, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, m.pair.as<int32_t>(), m.pairc.as<int32_t>(),
+                       ctx->my.inv_d.as<int32_t>(), nc);
 }
 
 extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
@@ -409,12 +423,11 @@ extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
         return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage: more than 5849 candidates in one instance");
     int rc = ultra_myers_stage_impl(ctx, in->arena, in->arena_len, np, in->q_off, in->q_len, in->t_off, in->t_len, in->k);
     if (rc != ULTRA_OK) return rc;
-    const MyersState &my = ctx->my;
     hipStream_t s = ctx->stream;
     const size_t NC = (size_t)std::max(nc, 1), NI = (size_t)std::max(ni, 1);
     ULTRA_HIP_CHECK(ctx, m.kind.ensure(NC)); ULTRA_HIP_CHECK(ctx, m.estart.ensure(NC * 4)); ULTRA_HIP_CHECK(ctx, m.estop.ensure(NC * 4));
     ULTRA_HIP_CHECK(ctx, m.pair.ensure(NC * 4)); ULTRA_HIP_CHECK(ctx, m.pairc.ensure(NC * 4));
-    ULTRA_HIP_CHECK(ctx, m.seqlen.ensure(NC * 4)); ULTRA_HIP_CHECK(ctx, m.seqid.ensure(NC * 4));
+    ULTRA_HIP_CHECK(ctx, m.seqlen.ensure(NC * 4)); ULTRA_HIP_CHECK(ctx, m.seqid.ensure(NC * 4)); ULTRA_HIP_CHECK(ctx, m.chr.ensure(NC * 4));
     ULTRA_HIP_CHECK(ctx, m.cap.ensure((NC + 1) * 8)); ULTRA_HIP_CHECK(ctx, m.capoff.ensure((NC + 1) * 8));
     ULTRA_HIP_CHECK(ctx, m.candoff.ensure((NI + 1) * 8)); ULTRA_HIP_CHECK(ctx, m.readlen.ensure(NI * 4));
     ULTRA_HIP_CHECK(ctx, m.fps.ensure(NI * 8)); ULTRA_HIP_CHECK(ctx, m.lps.ensure(NI * 8));
@@ -427,13 +440,13 @@ extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.estop.p, in->cand_e_stop, NC * 4, hipMemcpyHostToDevice, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pair.p, in->cand_pair, NC * 4, hipMemcpyHostToDevice, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.pairc.p, in->cand_pair_contained, NC * 4, hipMemcpyHostToDevice, s));
-        // candidate -> device pair order (the pairs were sorted on the device)
-        hipLaunchKernelGGL(k_remap_pairs, dim3((nc + 255) / 256), dim3(256), 0, s, m.pair.as<int32_t>(), m.pairc.as<int32_t>(),
-                           my.inv_d.as<int32_t>(), nc);
+        ultra_mam_remap_pairs(ctx, nc); // candidate -> device pair order (the pairs were sorted on the device)
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.seqlen.p, in->cand_seq_len, NC * 4, hipMemcpyHostToDevice, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.seqid.p, in->cand_seq_id, NC * 4, hipMemcpyHostToDevice, s));
+        if (in->cand_chr) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.chr.p, in->cand_chr, NC * 4, hipMemcpyHostToDevice, s));
     }
+    m.has_chr = in->cand_chr != nullptr;
     if (ni > 0) {
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.candoff.p, in->inst_cand_off, ((size_t)ni + 1) * 8, hipMemcpyHostToDevice, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.readlen.p, in->inst_read_len, (size_t)ni * 4, hipMemcpyHostToDevice, s));
@@ -501,6 +514,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     ULTRA_HIP_CHECK(ctx, m.cx.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.cy.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.cc.ensure(T * 4));
     ULTRA_HIP_CHECK(ctx, m.cd.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.cmsl.ensure(T * 4)); ULTRA_HIP_CHECK(ctx, m.ccand.ensure(T * 4));
     ULTRA_HIP_CHECK(ctx, m.cval.ensure(T * 8)); ULTRA_HIP_CHECK(ctx, m.cj.ensure(T * 4));
+    ULTRA_HIP_CHECK(ctx, m.ckind.ensure(T)); ULTRA_HIP_CHECK(ctx, m.cchr.ensure(T * 4));
     // ---- MAM lists ----
     MamArgs a;
     memset(&a, 0, sizeof a);
@@ -560,6 +574,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     g.mx = a.mx; g.my = a.my; g.mc = a.mc; g.md = a.md; g.mmsl = a.mmsl; g.mcand = a.mcand; g.mval = a.mval;
     g.cx = m.cx.as<int32_t>(); g.cy = m.cy.as<int32_t>(); g.cc = m.cc.as<int32_t>(); g.cd = m.cd.as<int32_t>();
     g.cmsl = m.cmsl.as<int32_t>(); g.ccand = m.ccand.as<int32_t>(); g.cval = m.cval.as<double>(); g.cj = m.cj.as<int32_t>(); g.n_inst = ni;
+    g.kind = m.kind.as<uint8_t>(); g.chr = m.has_chr ? m.chr.as<int32_t>() : nullptr; g.ckind = m.ckind.as<uint8_t>(); g.cchr = m.cchr.as<int32_t>();
     hipLaunchKernelGGL(k_chain_gather, dim3((ni + 3) / 4), dim3(256), 0, s, g);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[4], s));
@@ -586,6 +601,52 @@ extern "C" int ultra_mam_sizes(const ultra_ctx *ctx, int64_t *n_chain_total, int
     if (!ctx || !ctx->mam.ran) return ULTRA_E_STATE;
     if (n_chain_total) *n_chain_total = ctx->mam.total_chain;
     if (n_mam_total) *n_mam_total = ctx->mam.total_mam;
+    return ULTRA_OK;
+}
+
+extern "C" int ultra_mam_counts(const ultra_ctx *ctx, int32_t *n_inst, int32_t *n_cand, int32_t *n_pairs)
+{
+    if (!ctx || !ctx->mam.staged) return ULTRA_E_STATE;
+    if (n_inst) *n_inst = ctx->mam.n_inst;
+    if (n_cand) *n_cand = ctx->mam.n_cand;
+    if (n_pairs) *n_pairs = ctx->my.n_pairs;
+    return ULTRA_OK;
+}
+
+// The staged batch as the device holds it (pairs in their sorted order, cand_pair pointing into that order, offsets
+// relative to the arena's first byte): lets a test compare a device-planned batch with a host-planned one by content.
+extern "C" int ultra_mam_fetch_plan(ultra_ctx *ctx, int64_t *inst_cand_off, int32_t *inst_read_len, int64_t *inst_fps, int64_t *inst_lps,
+                                    uint8_t *cand_kind, int32_t *cand_e_start, int32_t *cand_e_stop, int32_t *cand_pair, int32_t *cand_pair_contained,
+                                    int32_t *cand_seq_len, int32_t *cand_seq_id, int32_t *cand_chr,
+                                    int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k)
+{
+    if (!ctx) return ULTRA_E_ARG;
+    MamState &m = ctx->mam;
+    MyersState &st = ctx->my;
+    if (!m.staged || !st.staged) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_fetch_plan: no staged batch");
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t ni = (size_t)m.n_inst, nc = (size_t)m.n_cand, np = (size_t)st.n_pairs;
+    ultra_drain_guard drain(ctx);
+    auto down = [&](void *dst, const DevBuf &src, size_t bytes) -> hipError_t {
+        if (!dst || bytes == 0) return hipSuccess;
+        return hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, s);
+    };
+    ULTRA_HIP_CHECK(ctx, down(inst_cand_off, m.candoff, (ni + 1) * 8));
+    ULTRA_HIP_CHECK(ctx, down(inst_read_len, m.readlen, ni * 4));
+    ULTRA_HIP_CHECK(ctx, down(inst_fps, m.fps, ni * 8)); ULTRA_HIP_CHECK(ctx, down(inst_lps, m.lps, ni * 8));
+    ULTRA_HIP_CHECK(ctx, down(cand_kind, m.kind, nc)); ULTRA_HIP_CHECK(ctx, down(cand_e_start, m.estart, nc * 4));
+    ULTRA_HIP_CHECK(ctx, down(cand_e_stop, m.estop, nc * 4)); ULTRA_HIP_CHECK(ctx, down(cand_pair, m.pair, nc * 4));
+    ULTRA_HIP_CHECK(ctx, down(cand_pair_contained, m.pairc, nc * 4)); ULTRA_HIP_CHECK(ctx, down(cand_seq_len, m.seqlen, nc * 4));
+    ULTRA_HIP_CHECK(ctx, down(cand_seq_id, m.seqid, nc * 4));
+    if (cand_chr && !m.has_chr) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_fetch_plan: the batch was staged without cand_chr");
+    ULTRA_HIP_CHECK(ctx, down(cand_chr, m.chr, nc * 4));
+    ULTRA_HIP_CHECK(ctx, down(q_off, st.qoff, np * 8)); ULTRA_HIP_CHECK(ctx, down(t_off, st.toff, np * 8));
+    ULTRA_HIP_CHECK(ctx, down(q_len, st.qlen, np * 4)); ULTRA_HIP_CHECK(ctx, down(t_len, st.tlen, np * 4)); ULTRA_HIP_CHECK(ctx, down(k, st.k, np * 4));
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    drain.dismiss();
+    if (q_off) for (size_t i = 0; i < np; i++) q_off[i] -= (int64_t)kArenaPad;
+    if (t_off) for (size_t i = 0; i < np; i++) t_off[i] -= (int64_t)kArenaPad;
     return ULTRA_OK;
 }
 
@@ -623,6 +684,11 @@ extern "C" int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out)
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->chain_msl, m.cmsl.p, TC * 4, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->chain_cand, m.ccand.p, TC * 4, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->chain_j, m.cj.p, TC * 4, hipMemcpyDeviceToHost, s));
+        if (out->chain_kind) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->chain_kind, m.ckind.p, TC, hipMemcpyDeviceToHost, s));
+        if (out->chain_chr) {
+            if (!m.has_chr) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_fetch: chain_chr asked for, but the batch was staged without cand_chr");
+            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->chain_chr, m.cchr.p, TC * 4, hipMemcpyDeviceToHost, s));
+        }
     }
     memcpy(out->n_mam, m.h_nmam.data(), (size_t)ni * 4);
     // optional: every instance's full, filtered and sorted MAM list (tests compare MAM sets)

@@ -1161,8 +1161,6 @@ const ClassDef kClasses[] = {
 static_assert(sizeof(kClasses) / sizeof(kClasses[0]) == kNumSizeClasses, "size_class_of() and kClasses must agree");
 constexpr int kNumClasses = sizeof(kClasses) / sizeof(kClasses[0]);
 constexpr int kMaxQuery = 64 * 64 * 8;
-constexpr int kMaxSymbols = 16;
-constexpr size_t kArenaPad = 64;
 
 template <int W, int MODE> hipError_t launch_lane(hipStream_t stream, const MyArgs &a, int64_t items, int max_waves)
 {
@@ -1396,6 +1394,19 @@ __global__ void __launch_bounds__(256) k_gather_work(const WorkItem *items, cons
 
 } // namespace
 
+void ultra_launch_presence(hipStream_t s, const uint8_t *raw, int64_t n, uint32_t *mask)
+{
+    if (n <= 0) return;
+    const unsigned gb = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_presence, dim3(gb), dim3(256), 0, s, raw, n, mask);
+}
+void ultra_launch_encode(hipStream_t s, const uint8_t *raw, int64_t n, const uint8_t *lut, uint8_t *seq, uint8_t *rseq, int64_t at, int64_t N)
+{
+    if (n <= 0) return;
+    const unsigned gb = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL(k_encode, dim3(gb), dim3(256), 0, s, raw, n, lut, seq, rseq, at, N);
+}
+
 // Orders the n_pairs pairs that lie UNSORTED in st.u_* (offsets relative to the arena's first byte) and builds the
 // forward work lists.  The arena (st.seq / st.rseq, st.N, st.S) must have been filled on ctx->stream before.
 int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
@@ -1530,6 +1541,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
     }
     hipStream_t s = ctx->stream;
     ultra_drain_guard drain(ctx);
+    st.pool_serial = 0; // this batch's arena replaces whatever resident pool the buffers held
     // ---- arena: raw bytes up, alphabet compaction (distinct bytes -> dense codes, comparisons stay byte-exact) ----
     const int64_t N = (int64_t)arena_len + 2 * (int64_t)kArenaPad;
     ULTRA_HIP_CHECK(ctx, st.raw.ensure(arena_len + 16));

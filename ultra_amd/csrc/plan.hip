@@ -17,35 +17,7 @@
 #include <unordered_map>
 #include <vector>
 
-namespace {
-
-struct Key3 {
-    int64_t a, b, c;
-    bool operator==(const Key3 &o) const { return a == o.a && b == o.b && c == o.c; }
-};
-struct Key3Hash {
-    size_t operator()(const Key3 &k) const
-    {
-        uint64_t h = (uint64_t)k.a * 0x9E3779B97F4A7C15ull;
-        h ^= (uint64_t)k.b + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h ^= (uint64_t)k.c + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        return (size_t)h;
-    }
-};
-struct Slice { int64_t off, len; }; // into the index pool
-
-} // namespace
-
-struct ultra_index {
-    std::vector<uint8_t> pool;
-    std::unordered_map<Key3, std::pair<int64_t, int64_t>, Key3Hash> part_segs; // part -> [begin, end) in seg_flat (triples)
-    std::vector<int64_t> seg_flat;
-    std::unordered_map<Key3, std::pair<int64_t, int64_t>, Key3Hash> seg_genes; // segment -> [begin, end) in gene_flat
-    std::vector<int32_t> gene_flat;
-    std::vector<std::pair<int64_t, int64_t>> gene_small;                       // gene -> [begin, end) in small_flat (triples)
-    std::vector<int64_t> small_flat;
-    std::unordered_map<Key3, Slice, Key3Hash> seg_seq, flank_seq;
-};
+#include "plan.h"
 
 struct ultra_plan {
     std::vector<uint8_t> arena;
@@ -353,6 +325,7 @@ extern "C" int ultra_plan_create(const ultra_index *ix, const ultra_plan_request
     in.n_inst = rq->n_inst;
     in.inst_cand_off = pl->cand_off.data(); in.inst_read_len = pl->read_len.data();
     in.inst_first_part_stop = pl->fps.data(); in.inst_last_part_start = pl->lps.data();
+    in.cand_chr = pl->chr.data();
     *out = pl;
     return ULTRA_OK;
 }

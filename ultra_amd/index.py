@@ -90,6 +90,51 @@ class NativePlan(object):
             pass
 
 
+def flatten_instances(instances, cache=None):
+    """(solution, read_seq) pairs -> the flat arrays of ultra_plan_request: (nam_off, nam_part[n, 3], nam_x, nam_y,
+    reads, read_off)."""
+    nam_off, part, xs, ys, reads = [0], [], [], [], []
+    cache = {} if cache is None else cache
+    for solution, read in instances:
+        for nam in solution:
+            pid = nam.exon_part_id
+            t = cache.get(pid)
+            if t is None:
+                f = pid.split('^')
+                t = cache[pid] = (int(f[0]), int(f[1]), int(f[2]))
+            part.append(t)
+            xs.append(nam.x); ys.append(nam.y)
+        nam_off.append(len(xs))
+        reads.append(read.encode() if isinstance(read, str) else bytes(read))
+    read_off = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum([len(b) for b in reads], out=read_off[1:])
+    return (np.asarray(nam_off, np.int64), np.asarray(part, np.int64).reshape(-1, 3), np.asarray(xs, np.int64),
+            np.asarray(ys, np.int64), np.frombuffer(b"".join(reads) or b"\0", dtype=np.uint8), read_off)
+
+
+class DeviceIndex(object):
+    """The packed index resident in the HBM of one GPU (ultra_dindex): what ultra_mam_stage_nams plans batches on."""
+
+    def __init__(self, native_index, device=0):
+        self._so = native_index._so
+        h = C.c_void_p()
+        rc = self._so.ultra_dindex_create(int(device), native_index.handle, C.byref(h))
+        if rc != 0:
+            raise _lib.UltraError(rc, self._so.ultra_dindex_last_error().decode())
+        self.handle, self.device = h, int(device)
+
+    def close(self):
+        if self.handle is not None:
+            self._so.ultra_dindex_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class NativeIndex(object):
     def __init__(self, ref_segment_sequences, ref_flank_sequences, parts_to_segments, segment_to_gene, gene_to_small_segments):
         self._so = _lib.load()
@@ -151,29 +196,13 @@ class NativeIndex(object):
         if rc != 0:
             raise _lib.UltraError(rc, self._so.ultra_plan_last_error().decode())
         self.handle = h
+        self.pool = pool   # the bytes the device index's pool offsets refer to (segments, then flanks)
         self.n_genes, self.pool_bytes = len(gene_no), size
         self._part_cache = {}
 
     def plan(self, instances):
         """instances: iterable of (solution, read_seq); solution = the NAM chain (objects with .x, .y, .exon_part_id)."""
-        nam_off, part, xs, ys, reads = [0], [], [], [], []
-        cache = self._part_cache
-        for solution, read in instances:
-            for nam in solution:
-                pid = nam.exon_part_id
-                t = cache.get(pid)
-                if t is None:
-                    f = pid.split('^')
-                    t = cache[pid] = (int(f[0]), int(f[1]), int(f[2]))
-                part.append(t)
-                xs.append(nam.x); ys.append(nam.y)
-            nam_off.append(len(xs))
-            reads.append(read.encode() if isinstance(read, str) else bytes(read))
-        read_off = np.zeros(len(reads) + 1, np.int64)
-        np.cumsum([len(b) for b in reads], out=read_off[1:])
-        return self.plan_arrays(np.asarray(nam_off, np.int64), np.asarray(part, np.int64).reshape(-1, 3),
-                                np.asarray(xs, np.int64), np.asarray(ys, np.int64),
-                                np.frombuffer(b"".join(reads) or b"\0", dtype=np.uint8), read_off)
+        return self.plan_arrays(*flatten_instances(instances, self._part_cache))
 
     def plan_arrays(self, nam_off, nam_part, nam_x, nam_y, reads, read_off):
         """The same from flat arrays (the fields of ultra_plan_request): no per-NAM Python work at all."""

@@ -25,6 +25,8 @@ EXPORTS = [
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
     "ultra_index_create", "ultra_index_destroy", "ultra_plan_create", "ultra_plan_input", "ultra_plan_cands",
     "ultra_plan_destroy", "ultra_plan_last_error",
+    "ultra_dindex_create", "ultra_dindex_destroy", "ultra_dindex_last_error", "ultra_mam_stage_nams", "ultra_mam_counts",
+    "ultra_mam_fetch_plan",
 ]
 
 
@@ -50,7 +52,7 @@ class MamInput(C.Structure):
                 ("n_cand", C.c_int32), ("cand_kind", _U8P), ("cand_e_start", _I32P), ("cand_e_stop", _I32P),
                 ("cand_pair", _I32P), ("cand_pair_contained", _I32P), ("cand_seq_len", _I32P), ("cand_seq_id", _I32P),
                 ("n_inst", C.c_int32), ("inst_cand_off", _I64P), ("inst_read_len", _I32P),
-                ("inst_first_part_stop", _I64P), ("inst_last_part_start", _I64P)]
+                ("inst_first_part_stop", _I64P), ("inst_last_part_start", _I64P), ("cand_chr", _I32P)]
 
 
 class MamOutput(C.Structure):
@@ -60,7 +62,7 @@ class MamOutput(C.Structure):
                 ("chain_msl", _I32P), ("chain_cand", _I32P), ("chain_j", _I32P),
                 ("mam_cap", C.c_int64), ("mam_off", _I64P),
                 ("mam_x", _I32P), ("mam_y", _I32P), ("mam_c", _I32P), ("mam_d", _I32P), ("mam_val", _F64P),
-                ("mam_msl", _I32P), ("mam_cand", _I32P)]
+                ("mam_msl", _I32P), ("mam_cand", _I32P), ("chain_kind", _U8P), ("chain_chr", _I32P)]
 
 
 class IndexInput(C.Structure):
@@ -131,6 +133,15 @@ def load():
     lib.ultra_plan_destroy.restype = None
     lib.ultra_plan_last_error.argtypes = []
     lib.ultra_plan_last_error.restype = C.c_char_p
+    lib.ultra_dindex_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.ultra_dindex_destroy.argtypes = [vp]
+    lib.ultra_dindex_destroy.restype = None
+    lib.ultra_dindex_last_error.argtypes = []
+    lib.ultra_dindex_last_error.restype = C.c_char_p
+    lib.ultra_mam_stage_nams.argtypes = [vp, vp, C.POINTER(PlanRequest)]
+    lib.ultra_mam_counts.argtypes = [vp, i32p, i32p, i32p]
+    lib.ultra_mam_fetch_plan.argtypes = [vp, i64p, i32p, i64p, i64p, u8p, i32p, i32p, i32p, i32p, i32p, i32p, i32p,
+                                         i64p, i32p, i64p, i32p, i32p]
     _lib = lib
     return lib
 
@@ -301,6 +312,53 @@ class Context(object):
         self._staged_n = int(inp.contents.n_pairs)
         self._check(self.lib.ultra_mam_stage(self._h, inp))
 
+    def mam_stage_nams(self, dindex, nam_off, nam_part, nam_x, nam_y, reads, read_off):
+        """Device-planned batch (ultra_mam_stage_nams): the NAM chains and reads of the instances as flat arrays (the
+        fields of ultra_plan_request); candidates and pairs are produced on the GPU over the resident index."""
+        a_off = _arr(nam_off, np.int64); a_part = _arr(nam_part, np.int64).ravel()
+        a_x = _arr(nam_x, np.int64); a_y = _arr(nam_y, np.int64)
+        a_reads = _arr(reads, np.uint8); a_roff = _arr(read_off, np.int64)
+        n_inst = len(a_roff) - 1
+        if len(a_off) != n_inst + 1 or len(a_part) != 3 * len(a_x) or len(a_x) != len(a_y) or (n_inst and a_off[-1] != len(a_x)):
+            raise ValueError("mam_stage_nams: inconsistent array lengths")
+        rq = PlanRequest()
+        rq.n_inst = n_inst; rq.inst_nam_off = _ptr(a_off, C.c_int64); rq.nam_part = _ptr(a_part, C.c_int64)
+        rq.nam_x = _ptr(a_x, C.c_int64); rq.nam_y = _ptr(a_y, C.c_int64)
+        rq.reads = _ptr(a_reads, C.c_uint8); rq.read_off = _ptr(a_roff, C.c_int64)
+        self._mam_n_inst = n_inst
+        self._check(self.lib.ultra_mam_stage_nams(self._h, dindex.handle, C.byref(rq)))
+        self._staged_n = self.mam_counts()[2]
+
+    def mam_counts(self):
+        """(instances, candidates, pairs) of the staged batch."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.ultra_mam_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def mam_fetch_plan(self):
+        """The staged batch's candidate / pair arrays as the device holds them (pairs in sorted order)."""
+        ni, nc, npairs = self.mam_counts()
+        r = {"inst_cand_off": np.zeros(ni + 1, np.int64), "inst_read_len": np.zeros(max(ni, 1), np.int32),
+             "inst_first_part_stop": np.zeros(max(ni, 1), np.int64), "inst_last_part_start": np.zeros(max(ni, 1), np.int64),
+             "cand_kind": np.zeros(max(nc, 1), np.uint8)}
+        for f in ("cand_e_start", "cand_e_stop", "cand_pair", "cand_pair_contained", "cand_seq_len", "cand_seq_id", "cand_chr"):
+            r[f] = np.zeros(max(nc, 1), np.int32)
+        r["q_off"] = np.zeros(max(npairs, 1), np.int64); r["t_off"] = np.zeros(max(npairs, 1), np.int64)
+        for f in ("q_len", "t_len", "k"):
+            r[f] = np.zeros(max(npairs, 1), np.int32)
+        self._check(self.lib.ultra_mam_fetch_plan(
+            self._h, _ptr(r["inst_cand_off"], C.c_int64), _ptr(r["inst_read_len"], C.c_int32), _ptr(r["inst_first_part_stop"], C.c_int64),
+            _ptr(r["inst_last_part_start"], C.c_int64), _ptr(r["cand_kind"], C.c_uint8), _ptr(r["cand_e_start"], C.c_int32),
+            _ptr(r["cand_e_stop"], C.c_int32), _ptr(r["cand_pair"], C.c_int32), _ptr(r["cand_pair_contained"], C.c_int32),
+            _ptr(r["cand_seq_len"], C.c_int32), _ptr(r["cand_seq_id"], C.c_int32), _ptr(r["cand_chr"], C.c_int32),
+            _ptr(r["q_off"], C.c_int64), _ptr(r["q_len"], C.c_int32), _ptr(r["t_off"], C.c_int64), _ptr(r["t_len"], C.c_int32),
+            _ptr(r["k"], C.c_int32)))
+        for f in list(r):
+            n = ni if f.startswith("inst_") and f != "inst_cand_off" else nc if f.startswith("cand_") else npairs if f in ("q_off", "t_off", "q_len", "t_len", "k") else None
+            if n is not None:
+                r[f] = r[f][:n]
+        return r
+
     def mam_run(self, min_acc):
         self._check(self.lib.ultra_mam_run(self._h, float(min_acc)))
 
@@ -309,8 +367,9 @@ class Context(object):
         self._check(self.lib.ultra_mam_last_timing(self._h, ms))
         return [ms[i] for i in range(3)]
 
-    def mam_fetch(self, want_all=False):
-        """Results of the last mam_run as numpy arrays (chains, and optionally the full MAM lists)."""
+    def mam_fetch(self, want_all=False, want_names=False):
+        """Results of the last mam_run as numpy arrays (chains, and optionally the full MAM lists).  want_names: also
+        chain_kind / chain_chr, from which the mam_id and ref_chr_id of every chain element follow."""
         ni = self._mam_n_inst
         nc, nm = C.c_int64(), C.c_int64()
         self._check(self.lib.ultra_mam_sizes(self._h, C.byref(nc), C.byref(nm)))
@@ -326,6 +385,9 @@ class Context(object):
         for f in ("x", "y", "c", "d", "msl", "cand", "j"):
             setattr(out, "chain_" + f, _ptr(r["chain_" + f], C.c_int32))
         out.chain_val = _ptr(r["chain_val"], C.c_double)
+        if want_names:
+            r["chain_kind"] = np.zeros(tc, np.uint8); r["chain_chr"] = np.zeros(tc, np.int32)
+            out.chain_kind, out.chain_chr = _ptr(r["chain_kind"], C.c_uint8), _ptr(r["chain_chr"], C.c_int32)
         if want_all:
             r["mam_off"] = np.zeros(ni + 1, np.int64)
             out.mam_off, out.mam_cap = _ptr(r["mam_off"], C.c_int64), tm
