@@ -326,6 +326,33 @@ int ultra_mam_fetch_plan(ultra_ctx *ctx, int64_t *inst_cand_off, int32_t *inst_r
                          int32_t *cand_seq_len, int32_t *cand_seq_id, int32_t *cand_chr,
                          int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k);
 
+/*
+ * Batch pipeline of one GPU - the device-side replacement of the reference's worker fan-out (modules/pc.py:78-83:
+ * nr_cores align_single processes on 1000-read batches).  `depth` slots (1..4), each with a context, a host thread
+ * and pinned result buffers, share one resident device index; a submitted batch walks stage (H2D, device plan, sort)
+ * -> run (kernels; one slot at a time) -> fetch (D2H into pinned memory) on its slot's thread, so the copies and the
+ * planning of one batch ride beside the kernels of another.  A batch whose instances exceed the device planner's
+ * envelope is planned on the host (ultra_plan_create) inside the slot; results do not depend on the route.
+ *   ultra_pipe_submit   enqueues a batch; the request's arrays must stay valid until the batch has been waited for;
+ *                       ULTRA_E_STATE when no slot is idle (a slot is busy from submit until release)
+ *   ultra_pipe_wait     blocks until the OLDEST submitted batch is done and lends out its results: `view` points
+ *                       into pinned memory of the slot (chain_* incl. chain_kind / chain_chr, value, n_mam, chain_off)
+ *   ultra_pipe_release  gives the slot back; the view is invalid afterwards
+ *   ultra_pipe_timing   of the batch currently lent out: host milliseconds [0] stage [1] waiting for the GPU
+ *                       [2] run [3] fetch, forward cells, and the device milliseconds of ultra_myers_last_timing /
+ *                       ultra_mam_last_timing
+ * One caller thread per pipe.  To keep two batches in flight while a third is being consumed use depth 3.
+ */
+typedef struct ultra_pipe ultra_pipe;
+int ultra_pipe_create(int device, const ultra_cfg *cfg, const ultra_index *idx, int32_t depth, ultra_pipe **out);
+void ultra_pipe_destroy(ultra_pipe *pipe);
+const char *ultra_pipe_last_error(const ultra_pipe *pipe);
+int ultra_pipe_submit(ultra_pipe *pipe, const ultra_plan_request *rq, double min_acc);
+int ultra_pipe_pending(const ultra_pipe *pipe);
+int ultra_pipe_wait(ultra_pipe *pipe, int32_t *n_inst, int64_t *n_chain, ultra_mam_output *view);
+int ultra_pipe_release(ultra_pipe *pipe);
+int ultra_pipe_timing(const ultra_pipe *pipe, float ms[4], double *cells, float myers_ms[5], float mam_ms[3]);
+
 #ifdef __cplusplus
 }
 #endif

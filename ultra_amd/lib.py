@@ -27,6 +27,8 @@ EXPORTS = [
     "ultra_plan_destroy", "ultra_plan_last_error",
     "ultra_dindex_create", "ultra_dindex_destroy", "ultra_dindex_last_error", "ultra_mam_stage_nams", "ultra_mam_counts",
     "ultra_mam_fetch_plan",
+    "ultra_pipe_create", "ultra_pipe_destroy", "ultra_pipe_last_error", "ultra_pipe_submit", "ultra_pipe_pending",
+    "ultra_pipe_wait", "ultra_pipe_release", "ultra_pipe_timing",
 ]
 
 
@@ -142,6 +144,16 @@ def load():
     lib.ultra_mam_counts.argtypes = [vp, i32p, i32p, i32p]
     lib.ultra_mam_fetch_plan.argtypes = [vp, i64p, i32p, i64p, i64p, u8p, i32p, i32p, i32p, i32p, i32p, i32p, i32p,
                                          i64p, i32p, i64p, i32p, i32p]
+    lib.ultra_pipe_create.argtypes = [C.c_int, C.POINTER(Cfg), vp, C.c_int32, C.POINTER(vp)]
+    lib.ultra_pipe_destroy.argtypes = [vp]
+    lib.ultra_pipe_destroy.restype = None
+    lib.ultra_pipe_last_error.argtypes = [vp]
+    lib.ultra_pipe_last_error.restype = C.c_char_p
+    lib.ultra_pipe_submit.argtypes = [vp, C.POINTER(PlanRequest), C.c_double]
+    lib.ultra_pipe_pending.argtypes = [vp]
+    lib.ultra_pipe_wait.argtypes = [vp, i32p, i64p, C.POINTER(MamOutput)]
+    lib.ultra_pipe_release.argtypes = [vp]
+    lib.ultra_pipe_timing.argtypes = [vp, C.POINTER(C.c_float), f64p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -431,6 +443,86 @@ class Context(object):
                                                     _ptr(d, C.c_int32), None if mi is None else _ptr(mi, C.c_int64), solver,
                                                     _ptr(Cv, C.c_int64), _ptr(tr, C.c_int32), _ptr(value, C.c_int64)))
         return Cv[:len(c) + ni], tr[:len(c) + ni], value[:ni]
+
+
+class Pipe(object):
+    """ultra_pipe: `depth` batches in flight on one GPU (stage | run | fetch of consecutive batches overlap).
+
+        pipe = Pipe(native_index, device=0, depth=3)
+        pipe.submit(nam_off, nam_part, nam_x, nam_y, reads, read_off, min_acc)      # returns at once
+        res = pipe.wait()          # oldest batch: dict of numpy views into pinned memory ...
+        pipe.release()             # ... valid until here
+    """
+
+    def __init__(self, native_index, device=0, depth=3, cfg=None):
+        self.lib = load()
+        self._h = C.c_void_p()
+        c = Cfg()
+        self.lib.ultra_cfg_default(C.byref(c))
+        for k, v in (cfg or {}).items():
+            setattr(c, k, v)
+        self._index = native_index      # the pipe reads the host index when it has to plan a batch on the host
+        self._keep = []
+        rc = self.lib.ultra_pipe_create(int(device), C.byref(c), native_index.handle, int(depth), C.byref(self._h))
+        if rc != ULTRA_OK:
+            raise UltraError(rc, "ultra_pipe_create(device=%d, depth=%d) failed" % (device, depth))
+        self.depth = int(depth)
+
+    def close(self):
+        if self._h:
+            self.lib.ultra_pipe_destroy(self._h)
+            self._h = C.c_void_p()
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != ULTRA_OK:
+            raise UltraError(rc, (self.lib.ultra_pipe_last_error(self._h) or b"").decode())
+
+    def pending(self):
+        return self.lib.ultra_pipe_pending(self._h)
+
+    def submit(self, nam_off, nam_part, nam_x, nam_y, reads, read_off, min_acc):
+        arrs = (_arr(nam_off, np.int64), _arr(nam_part, np.int64).ravel(), _arr(nam_x, np.int64), _arr(nam_y, np.int64),
+                _arr(reads, np.uint8), _arr(read_off, np.int64))
+        rq = PlanRequest()
+        rq.n_inst = len(arrs[5]) - 1
+        rq.inst_nam_off = _ptr(arrs[0], C.c_int64); rq.nam_part = _ptr(arrs[1], C.c_int64)
+        rq.nam_x = _ptr(arrs[2], C.c_int64); rq.nam_y = _ptr(arrs[3], C.c_int64)
+        rq.reads = _ptr(arrs[4], C.c_uint8); rq.read_off = _ptr(arrs[5], C.c_int64)
+        self._check(self.lib.ultra_pipe_submit(self._h, C.byref(rq), float(min_acc)))
+        self._keep.append(arrs)         # the library reads them until the batch has been waited for
+
+    def wait(self):
+        ni, nc = C.c_int32(), C.c_int64()
+        v = MamOutput()
+        rc = self.lib.ultra_pipe_wait(self._h, C.byref(ni), C.byref(nc), C.byref(v))
+        if self._keep:
+            self._keep.pop(0)
+        self._check(rc)
+        n, t = ni.value, nc.value
+
+        def view(ptr, cnt, dt):
+            return np.ctypeslib.as_array(ptr, shape=(cnt,)).view(dt) if cnt > 0 else np.zeros(0, dt)
+        r = {"value": view(v.value, n, np.float64), "n_mam": view(v.n_mam, n, np.int32), "chain_off": view(v.chain_off, n + 1, np.int64),
+             "chain_val": view(v.chain_val, t, np.float64), "chain_kind": view(v.chain_kind, t, np.uint8)}
+        for f in ("x", "y", "c", "d", "msl", "cand", "j", "chr"):
+            r["chain_" + f] = view(getattr(v, "chain_" + f), t, np.int32)
+        return r
+
+    def release(self):
+        self._check(self.lib.ultra_pipe_release(self._h))
+
+    def timing(self):
+        ms = (C.c_float * 4)(); my = (C.c_float * 5)(); mm = (C.c_float * 3)(); cells = C.c_double()
+        self._check(self.lib.ultra_pipe_timing(self._h, ms, C.byref(cells), my, mm))
+        return {"stage_ms": ms[0], "wait_ms": ms[1], "run_ms": ms[2], "fetch_ms": ms[3], "cells": cells.value,
+                "myers_ms": [my[i] for i in range(5)], "mam_ms": [mm[i] for i in range(3)]}
 
 
 _default_ctx = None
