@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the MAM stage (uLTRA's per-read alignment core) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads B] [--preset ont_cdna]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of B synthetic (read, NAM chain) instances
-whose candidate (segment, read) pairs are already resident in HBM: Myers forward / start / traceback
-kernels, MAM materialisation, chaining.  Workload = BASELINE.json configs[2] in its self-generated
-synthetic form (ONT cDNA-like reads, ~7 % errors, ~1 kb): GRCh38/GENCODE do not
-exist offline.  Reads are independent, so with N > 1 every rank runs its own shard (weak scaling, no
-data-path collective; torch.distributed is used for the barrier and the max-over-ranks time only).
+Workload = BASELINE.json configs[2] in its self-generated synthetic form (GRCh38 / GENCODE do
+not exist offline): a GENCODE-shaped annotation of ~60 000 genes on 24 chromosomes with overlapping genes
+(ultra_amd/synth.py WORLDS["c3"]) and 1 000 000 DISTINCT simulated ONT-cDNA reads per GPU (7 % errors, N(1000, 400),
+the reference simulator's error mix) as 4 batches of 262 144, each with its NAM chain.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the Myers forward pass (one kernel template, launched once per register bucket, the launches of
-                a step running concurrently): integer-VALU bound, achieved = 0.75 int32-op/cell * forward cells
-                of the step / HIP-event time from the first launch's start to the last one's end;
-                `largest_instantiation` = the same for the single biggest launch (shares the chip meanwhile)
-  cpu_baseline  the CPU oracle (oracle/, "port") timed on a bounded sample on the host cores
+A "step" is one pass of the hot path over one batch whose inputs are already resident in HBM: Myers forward / start /
+traceback kernels, MAM materialisation, chaining (ultra_mam_run).  The batches are planned on the device
+(ultra_mam_stage_nams over the resident index) into one context each before the timed region; the timed steps cycle
+through them, so no batch is replayed back to back.  Reads are independent: with N > 1 the job is N x 4 batches dealt
+round-robin over the ranks (ultra_amd/shard.py), weak scaling, no data-path collective; torch.distributed only
+provides the barrier and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      the Myers forward pass (one kernel template, launched once per register bucket, the launches of a step
+                running concurrently): integer-VALU bound, achieved = 0.75 int32-op/cell * forward cells of the step /
+                HIP-event time from the first launch's start to the last one's end
+  cpu_baseline  the CPU oracle (oracle/, "port") on a bounded sample of the same reads: all cores (pool capped at the
+                box's CPU share of 16) as `value`, one thread beside it
+  end_to_end    NOT `value`: reads/s from host arrays (NAM chains + reads) to fetched results through ultra_pipe
+                (H2D, device plan, sort, kernels, D2H; `depth` batches in flight), plus what a synchronous caller sees
+  micro         the four kernel-only Myers micro-benchmarks of SURVEY.md section 8d with per-class TCUPS / fraction
 """
 import argparse
 import json
@@ -24,40 +32,49 @@ import os
 import sys
 import time
 
-# Eight hardware queues instead of HIP's default four: the launches of one pass (five forward buckets, seven
-# traceback kernels) then all run side by side.  Must be in the environment before the first HIP call.
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("ULTRA_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
+from ultra_amd import hwq  # noqa: E402
+
+# One hardware queue per launch lane (the launches of a pass run side by side); must be in the environment before the
+# first HIP call.  --hw-queues / ULTRA_HW_QUEUES=4 gives the line a caller gets that initialised HIP with its defaults.
+for i, a in enumerate(sys.argv):
+    if a == "--hw-queues" and i + 1 < len(sys.argv):
+        os.environ["ULTRA_HW_QUEUES"] = sys.argv[i + 1]
+    elif a.startswith("--hw-queues="):
+        os.environ["ULTRA_HW_QUEUES"] = a.split("=", 1)[1]
+HW_QUEUES = hwq.export_hw_queues()
+
+import numpy as np  # noqa: E402
 
 OPS_PER_CELL = 0.75          # SURVEY.md section 8d convention: 48 int32 VALU ops per 64-cell block column
 PEAK_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: max clock
 LANES_PER_CU_CLK = 128       # 4 SIMD-32 per CU (MI355X_MICROARCH.md "CU = 4 x SIMD-32")
 HBM_PEAK_GBS = 8000.0
+CPU_SHARE = 16               # host cores that go with one GPU of the box (task statement)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=262144, help="reads (instances) per step and per GPU")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--reads", type=int, default=262144, help="reads (instances) per batch")
+    ap.add_argument("--batches", type=int, default=4, help="distinct batches per GPU (default: 4 x 262144 = 1M reads)")
     ap.add_argument("--preset", default="ont_cdna", choices=["ont_cdna", "isoseq", "ont_drna"])
-    ap.add_argument("--genes", type=int, default=1500)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
-    ap.add_argument("--cpu-workers", type=int, default=0, help="0 = min(16, available cores)")
-    ap.add_argument("--contexts", type=int, default=1, help="independent library contexts (host threads) per GPU; "
-                    "each runs 1/N of the step's reads so that the passes of different sub-batches overlap")
-    ap.add_argument("--stagger-ms", type=float, default=4.0, help="start offset between the contexts' loops (--contexts > 1)")
-    ap.add_argument("--lanes", type=int, default=0, help="launch lanes (HIP streams) per context, 0 = library default (4)")
+    ap.add_argument("--world", default="c3", choices=["c3", "c2", "small"])
+    ap.add_argument("--genes", type=int, default=0, help="override the annotation's gene count")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (0 = skip)")
+    ap.add_argument("--e2e-rounds", type=int, default=2, help="passes over the batches through ultra_pipe (0 = skip)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight in the end-to-end leg")
+    ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
+    ap.add_argument("--micro-scale", type=float, default=1.0, help="fraction of the micro-benchmarks' pair counts")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (default 8)")
+    ap.add_argument("--lanes", type=int, default=0, help="launch lanes (HIP streams) per context, 0 = one per hardware queue")
     ap.add_argument("--slots", type=int, default=0, help="end positions kept per pair in the first pass, 0 = library default")
-    ap.add_argument("--planner", default="native", choices=["native", "python"],
-                    help="host-side candidate enumeration: packed index + csrc/plan.hip, or the Python port")
-    ap.add_argument("--check", type=int, default=64, help="instances of the last step verified against the oracle")
+    ap.add_argument("--check", type=int, default=48, help="instances verified against the oracle (rank 0)")
     return ap.parse_args()
 
 
@@ -80,19 +97,53 @@ def cpu_baseline(idx, insts, min_acc, seconds, workers, cells_per_read):
     from oracle import cport
     cport.lib()
     _CPU.update(idx=idx, insts=insts, min_acc=min_acc)
-    # calibrate on a few instances, then size the sample to `seconds` of wall time
-    t = _cpu_worker(range(min(32, len(insts))))
-    per = t / min(32, len(insts))
-    n = int(max(workers * 8, seconds / per * workers))   # wraps around the batch when it is smaller than the sample
+    n_cal = min(24, len(insts))
+    per = _cpu_worker(range(n_cal)) / n_cal                     # calibrate, then size both samples to `seconds`
+    n1 = int(max(8, min(len(insts), seconds / per)))
+    t1 = _cpu_worker(range(n1))
+    n = int(max(workers * 8, seconds / per * workers))          # wraps around the sample when it is smaller
     chunks = [[i % len(insts) for i in range(j, n, workers)] for j in range(workers)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(workers) as pool:
         pool.map(_cpu_worker, chunks)
     wall = time.perf_counter() - t0
     return {"value": n / wall, "unit": "reads/s", "cores": workers, "kind": "port",
-            "sample": "%d reads of the same synthetic batch through oracle/classify_port.py + liboracle.so "
-                      "(C Myers bit-vector + chainers), %d fork workers, %.1f s wall" % (n, workers, wall),
-            "gcups": n * cells_per_read / wall * 1e-9}
+            "sample": "%d reads of batch 0 through oracle/classify_port.py + liboracle.so (C Myers bit-vector without an "
+                      "Ukkonen band + chainers), %d fork workers (pool capped at the box's CPU share of %d; %d cores "
+                      "visible), %.1f s wall" % (n, workers, CPU_SHARE, len(os.sched_getaffinity(0)), wall),
+            "gcups": n * cells_per_read / wall * 1e-9,
+            "one_thread": {"value": n1 / t1, "unit": "reads/s", "cores": 1, "gcups": n1 * cells_per_read / t1 * 1e-9,
+                           "sample": "%d reads, %.1f s" % (n1, t1)},
+            "reference_cli": "uLTRA align not present on the box (edlib, namfinder, minimap2 are not installable offline)"}
+
+
+def micro_benchmarks(lib, ctx, peak_tops, err, scale):
+    """kernel-only Myers micro-benchmarks through the C-ABI (ultra_myers_stage / _run)."""
+    from ultra_amd import synth
+    out = {}
+    for name in synth.MICRO:
+        n = max(1024, int(synth.MICRO[name]["n_pairs"] * scale))
+        pairs = synth.make_micro_pairs(name, err=err, planted=0.5, n_pairs=n)
+        ctx.myers_stage(*pairs)
+        ctx.myers_run()
+        best = None
+        for _ in range(3):
+            ctx.myers_run()
+            cells, ms = ctx.myers_timing()
+            if best is None or ms[4] < best[1][4]:
+                best = (cells, ms, ctx.myers_class_timing())
+        cells, ms, cls = best
+        fwd_tcups = cells / (ms[4] * 1e-3) * 1e-12 if ms[4] > 0 else None
+        res = ctx.myers_fetch()
+        out[name] = {
+            "pairs": int(len(pairs[5])), "cells": cells, "hit_fraction": float((res["ed"] >= 0).mean()),
+            "forward_ms": ms[4], "starts_ms": ms[1], "traceback_ms": ms[2], "all_passes_ms": ms[3],
+            "forward_tcups": fwd_tcups, "forward_frac_of_int32_valu_peak": OPS_PER_CELL * fwd_tcups / peak_tops if fwd_tcups else None,
+            "all_passes_tcups": cells / (ms[3] * 1e-3) * 1e-12 if ms[3] > 0 else None,
+            "forward_buckets": {"bucket%d_wmax%d" % k: {"cells": v[0], "ms": v[1], "tcups": v[0] / v[1] * 1e-9 if v[1] > 0 else None}
+                                for k, v in sorted(cls.items())},
+        }
+    return out
 
 
 def main():
@@ -100,31 +151,42 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    from ultra_amd import synth
     from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import index as native_index
+    from ultra_amd import shard, synth
 
-    # ---- synthetic workload (same world on every rank, a different read shard per rank) ----------
+    # ---- synthetic workload: the same annotation on every rank, the job's batches dealt over the ranks ----
     P = synth.PRESETS[args.preset]
-    w = synth.make_world(seed=20241008, n_genes=args.genes, n_chr=8)
+    wkw = dict(synth.WORLDS[args.world])
+    if args.genes:
+        wkw["n_genes"] = args.genes
+    t0 = time.perf_counter()
+    w = synth.make_world(seed=20241008, **wkw)
     idx = w.index()
-    insts = synth.make_instances(w, args.reads, seed=1000 + rank, preset=args.preset)
+    flat = synth.FlatWorld(w)
+    world_s = time.perf_counter() - t0
+    my_batches = shard.deal_batches(world * args.batches, rank, world, batch=1)     # batch ids of this rank
+    t0 = time.perf_counter()
+    sets = [synth.make_reads_native(flat, args.reads, seed=1000 + b, preset=args.preset, threads=CPU_SHARE) for b in my_batches]
+    reads_s = time.perf_counter() - t0
     import torch  # noqa: F401  (before libultra_hip.so is loaded: both must end up on the same HIP runtime - torch's)
-    t_plan = time.perf_counter()
-    if args.planner == "native" and args.contexts <= 1:
-        from ultra_amd import index as native_index
-        nix = native_index.NativeIndex(*idx)
-        t_plan = time.perf_counter()
-        batch = nix.plan([(sol, read) for read, sol, _ in insts])
-    else:
-        batch = stage.prepare_batch([(sol, read) for read, sol, _ in insts], *idx)
-    plan_s = time.perf_counter() - t_plan
-    cells = batch.cells
+    t0 = time.perf_counter()
+    nix = native_index.NativeIndex(*idx)
+    index_s = time.perf_counter() - t0
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        workers = args.cpu_workers or max(1, min(16, len(os.sched_getaffinity(0))))
-        cpu = cpu_baseline(idx, insts, P["min_acc"], args.cpu_seconds, workers, cells / float(len(insts)))
+        workers = max(1, min(CPU_SHARE, len(os.sched_getaffinity(0))))
+        n_sample = min(len(sets[0]), 4096)
+        sample = [sets[0].instance(i) for i in range(n_sample)]
+        # forward cells per read of the sample, from the host planner (the figure the GPU side reports per batch)
+        s0 = sets[0].slice(0, n_sample)
+        pl = nix.plan_arrays(s0.nam_off, s0.nam_part.reshape(-1, 3), s0.nam_x, s0.nam_y, s0.reads, s0.read_off)
+        cells_per_read = pl.cells / float(n_sample)
+        pl.close()
+        cpu = cpu_baseline(idx, sample, P["min_acc"], args.cpu_seconds, workers, cells_per_read)
 
-    # ---- GPU ---------------------------------------------------------------------------------------
+    # ---- GPU: bind the rank's device before anything else touches HIP ----
     import torch
     import torch.distributed as dist
     from ultra_amd import lib
@@ -133,135 +195,147 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    import threading
-    NC = max(1, args.contexts)
     cfg = {}
     if args.lanes:
         cfg["launch_lanes"] = args.lanes
     if args.slots:
         cfg["loc_slots"] = args.slots
-    ctxs = [lib.Context(local, cfg=cfg or None) for _ in range(NC)]
-    ctx = ctxs[0]
-    info = ctx.device_info()
-    if NC == 1:
-        batches = [batch]
-    else:
-        batches = [stage.pack_plans(batch.plans[i::NC]) for i in range(NC)]
-    for c, b in zip(ctxs, batches):
-        stage.stage_batch(c, b)
+    t0 = time.perf_counter()
+    dix = native_index.DeviceIndex(nix, local)
+    dindex_s = time.perf_counter() - t0
+    ctxs = [lib.Context(local, cfg=cfg or None) for _ in sets]
+    info = ctxs[0].device_info()
+    stage_ms = []
+    for c, rs in zip(ctxs, sets):
+        t0 = time.perf_counter()
+        c.mam_stage_nams(dix, rs.nam_off, rs.nam_part, rs.nam_x, rs.nam_y, rs.reads, rs.read_off)
+        stage_ms.append((time.perf_counter() - t0) * 1e3)
+    counts = [c.mam_counts() for c in ctxs]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_all():
-        if NC == 1:
-            stage.run_staged(ctx, P["min_acc"])
-            return
-        errs = []
-
-        def work(c):
-            try:
-                stage.run_staged(c, P["min_acc"])
-            except Exception as e:   # surfaced below
-                errs.append(e)
-        th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-
-    for _ in range(args.warmup):
-        run_all()
+    nb = len(ctxs)
+    for i in range(args.warmup):
+        ctxs[i % nb].mam_run(P["min_acc"])
+    # once more, staged a second time: what a batch costs to stage when the buffers exist already
+    t0 = time.perf_counter()
+    ctxs[0].mam_stage_nams(dix, sets[0].nam_off, sets[0].nam_part, sets[0].nam_x, sets[0].nam_y, sets[0].reads, sets[0].read_off)
+    restage_ms = (time.perf_counter() - t0) * 1e3
+    ctxs[0].mam_run(P["min_acc"])
     class_ms = {}
-    fwd_ms = rev_ms = tb_ms = all_ms = fwdk_ms = 0.0
-    build_ms = chain_ms = gather_ms = 0.0
+    acc = {"fwd": 0.0, "rev": 0.0, "tb": 0.0, "all": 0.0, "fwdk": 0.0, "build": 0.0, "chain": 0.0, "gather": 0.0}
+    cells_run = 0.0
     barrier()
     t0 = time.perf_counter()
-
-    def collect(c):
-        nonlocal fwd_ms, rev_ms, tb_ms, all_ms, fwdk_ms, build_ms, chain_ms, gather_ms
-        _, ms = c.myers_timing()
-        fwd_ms += ms[0]; rev_ms += ms[1]; tb_ms += ms[2]; all_ms += ms[3]; fwdk_ms += ms[4]
+    for i in range(args.steps):
+        c = ctxs[i % nb]
+        c.mam_run(P["min_acc"])
+        cells, ms = c.myers_timing()
+        cells_run += cells
+        acc["fwd"] += ms[0]; acc["rev"] += ms[1]; acc["tb"] += ms[2]; acc["all"] += ms[3]; acc["fwdk"] += ms[4]
         mm = c.mam_timing()
-        build_ms += mm[0]; chain_ms += mm[1]; gather_ms += mm[2]
+        acc["build"] += mm[0]; acc["chain"] += mm[1]; acc["gather"] += mm[2]
         for key, (cc, t) in c.myers_class_timing().items():
             a = class_ms.setdefault(key, [0.0, 0.0, 0])
             a[0] += cc; a[1] += t; a[2] += 1
-
-    if NC == 1:
-        for _ in range(args.steps):
-            run_all()
-            collect(ctx)
-    else:
-        # Sub-batches in flight on one GPU: every context runs its K steps back to back from its own host thread,
-        # started half a pass apart, so that the latency-bound passes of one (traceback, MAM build, chaining)
-        # overlap with the throughput-bound ones (forward, starts) of the other.
-        errs, lock = [], threading.Lock()
-
-        def loop(i, c):
-            try:
-                time.sleep(i * args.stagger_ms * 1e-3)
-                for _ in range(args.steps):
-                    stage.run_staged(c, P["min_acc"])
-                    with lock:
-                        collect(c)
-            except Exception as e:   # surfaced below
-                errs.append(e)
-        th = [threading.Thread(target=loop, args=(i, c)) for i, c in enumerate(ctxs)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
     barrier()
     elapsed = time.perf_counter() - t0
-    # results back to the host (PCIe; outside the timed region, reported separately)
-    t1 = time.perf_counter()
-    ress = [c.mam_fetch() for c in ctxs]
-    fetch_s = time.perf_counter() - t1
-    t1 = time.perf_counter()
-    outs = [stage.results_to_python(b, r) for b, r in zip(batches, ress)]
-    topy_s = time.perf_counter() - t1
-    out = [None] * len(insts)
-    for i in range(NC):
-        out[i::NC] = outs[i]
-    res = {"chain_off": [sum(int(r["chain_off"][-1]) for r in ress)]}
-    from ultra_amd import shard
-    elapsed, reads_all, cells_all = shard.reduce_job(elapsed, len(insts), cells, device="cuda" if world > 1 else None)
+    K = args.steps
+    elapsed, reads_all, cells_all = shard.reduce_job(elapsed, args.reads * K, cells_run, device="cuda" if world > 1 else None)
 
-    # ---- parity spot check of the timed output (oracle = checker only) ---------------------------
+    # ---- results back to the host (PCIe; outside the timed region) + parity spot check against the oracle ----
+    t1 = time.perf_counter()
+    res0 = ctxs[0].mam_fetch(want_names=True)
+    fetch_s = time.perf_counter() - t1
+    # Algorithmic HBM bytes of a step: m + n sequence bytes + 40 B descriptor / result header per pair
+    alg_bytes = None
+    if rank == 0:
+        plan0 = ctxs[0].mam_fetch_plan()
+        alg_bytes = int(plan0["q_len"].astype(np.int64).sum() + plan0["t_len"].astype(np.int64).sum() + 40 * len(plan0["k"]))
+        del plan0
     checked = 0
     if rank == 0 and args.check > 0:
         import struct
         from oracle import classify_port
-        for i in range(0, len(insts), max(1, len(insts) // args.check)):
-            read, sol, _ = insts[i]
+        t1 = time.perf_counter()
+        out0 = stage.results_from_names(res0, np.diff(sets[0].read_off).tolist())
+        topy_s = time.perf_counter() - t1
+        for i in range(0, len(sets[0]), max(1, len(sets[0]) // args.check)):
+            read, sol, _ = sets[0].instance(i)
             want = classify_port.classify(sol, *idx, read, None, P["min_acc"])
-            g = out[i]
+            g = out0[i]
             ok = (want[0] == g[0] and struct.pack("d", float(want[1])) == struct.pack("d", float(g[1]))
                   and tuple(tuple(m) for m in want[2]) == tuple(tuple(m) for m in g[2]))
             if not ok:
                 raise SystemExit("bench.py: instance %d differs from the oracle - refusing to report a number" % i)
             checked += 1
+    else:
+        topy_s = 0.0
+
+    # ---- end to end: host arrays -> ultra_pipe -> fetched results (NOT `value`) ----
+    e2e = None
+    if args.e2e_rounds > 0:
+        for c in ctxs[1:]:
+            c.close()                       # the pipe's slots bring their own contexts
+        ctxs = ctxs[:1]
+        pipe = lib.Pipe(nix, local, depth=args.depth, cfg=cfg or None)
+
+        def submit(b):
+            rs = sets[b % nb]
+            pipe.submit(rs.nam_off, rs.nam_part, rs.nam_x, rs.nam_y, rs.reads, rs.read_off, P["min_acc"])
+        for b in range(2 * args.depth):     # every slot allocates its buffers on its first batches
+            submit(b)
+            if pipe.pending() >= args.depth:
+                pipe.wait(); pipe.release()
+        while pipe.pending():
+            pipe.wait(); pipe.release()
+        total = args.e2e_rounds * nb
+        sent = done = 0
+        tims, chains = [], 0
+        barrier()
+        t0 = time.perf_counter()
+        while done < total:
+            while sent < total and sent - done < args.depth:
+                submit(sent); sent += 1
+            r = pipe.wait()
+            chains += int(r["chain_off"][-1])
+            tims.append(pipe.timing())
+            pipe.release(); done += 1
+        barrier()
+        e2e_s = time.perf_counter() - t0
+        pipe.close()
+        e2e_s, e2e_reads, _ = shard.reduce_job(e2e_s, args.reads * total, 0.0, device="cuda" if world > 1 else None)
+        avg = lambda k: sum(t[k] for t in tims) / len(tims)
+        e2e = {"reads_per_s": e2e_reads / e2e_s, "batches": total, "reads_per_batch": args.reads, "depth": args.depth,
+               "host_threads": args.depth, "input": "NAM chains + reads as flat host arrays (pageable)",
+               "output": "chains with kind / chromosome in pinned host memory", "per_batch_ms": {
+                   "stage_h2d_device_plan_sort": avg("stage_ms"), "waiting_for_gpu": avg("wait_ms"), "run": avg("run_ms"), "fetch_d2h": avg("fetch_ms")},
+               "chain_rows_fetched": chains,
+               "synchronous_caller_reads_per_s": args.reads / ((restage_ms + elapsed / K * 1e3 + fetch_s * 1e3) * 1e-3)}
+
+    micro = None
+    if rank == 0 and args.micro:
+        peak_tops = info["n_cu"] * LANES_PER_CU_CLK * PEAK_CLOCK_GHZ * 1e9 * 1e-12
+        micro = micro_benchmarks(lib, ctxs[0], peak_tops, P["err"], args.micro_scale)
 
     if rank == 0:
-        K = args.steps
         peak_ops = info["n_cu"] * LANES_PER_CU_CLK * PEAK_CLOCK_GHZ * 1e9
+        n_pairs = float(np.mean([c[2] for c in counts]))
+        n_cands = float(np.mean([c[1] for c in counts]))
+        cells_step = cells_all / world / K
         dom = max(class_ms.items(), key=lambda kv: kv[1][1]) if class_ms else None
         roof = None
         if dom:
             (G, Wd), (c, ms, launches) = dom
-            ops_per_launch = OPS_PER_CELL * c / launches
-            dur = ms / launches * 1e-3
-            achieved = ops_per_launch / dur * 1e-12
+            achieved = OPS_PER_CELL * c / launches / (ms / launches * 1e-3) * 1e-12
             kname = "myers_mega<0, %d>" % G   # forward pass (MODE 0) of register bucket G
-            # HBM bytes from the committed rocprofv3 --pmc passes of this same command (profiles/)
+            # HBM bytes from the committed rocprofv3 --pmc passes of this command (profiles/); not measured in-run:
+            # counters need the profiler.  The record names its command and date.
             traffic = fam_traffic = None
+            traffic_src = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
@@ -269,57 +343,66 @@ def main():
                     if rec.get("dominant_kernel") == kname:
                         traffic = rec.get("hbm_bytes_per_launch")
                     fam_traffic = rec.get("forward_family", {}).get("hbm_bytes_per_step")
+                    traffic_src = {"file": "profiles/pmc_latest.json", "recorded": rec.get("recorded"), "command": rec.get("command")}
                 except Exception:
                     traffic = fam_traffic = None
             # The forward pass is ONE kernel template instantiated per register bucket; the (up to 5) instantiations
             # of a step are launched together on their own streams and share the CUs, so the duration of a single one says
             # how long it shared the chip, not how fast it is.  The roofline is therefore taken over the family:
             # all forward cells of the step / (first launch start -> last launch end, HIP events on those streams).
-            # The largest single instantiation, whose avg duration is the one rocprofv3 --stats lists, is kept below.
-            fam_ms = fwdk_ms / K / max(1, args.contexts)
-            fam_ach = OPS_PER_CELL * (cells_all / world) / (fam_ms * 1e-3) * 1e-12 if fam_ms > 0 else 0.0
+            fam_ms = acc["fwdk"] / K
+            fam_ach = OPS_PER_CELL * cells_step / (fam_ms * 1e-3) * 1e-12 if fam_ms > 0 else 0.0
+            whole_ach = OPS_PER_CELL * cells_step / (acc["all"] / K * 1e-3) * 1e-12 if acc["all"] > 0 else 0.0
             roof = {"bound": "valu_int32", "kernel": "myers_mega<0, 0..4> (forward pass: concurrent launches, one per register bucket)",
                     "achieved": fam_ach, "peak": peak_ops * 1e-12, "unit": "Tops/s", "frac": fam_ach / (peak_ops * 1e-12),
-                    "traffic": fam_traffic, "cells_per_launch": cells_all / world, "avg_launch_ms": fam_ms,
+                    "traffic": fam_traffic, "traffic_source": traffic_src, "cells_per_launch": cells_step, "avg_launch_ms": fam_ms,
                     "ops_per_cell": OPS_PER_CELL,
                     # profiles/r01_valu_issue_rate.txt: a SIMD issues one plain 32-bit VALU instruction per 2.44 cycles of
-                    # the nominal 2.4 GHz under this kind of load (the chip down-clocks), three-source ALU ops
-                    # (v_alignbit / v_lshl_or / v_add3) and 64-bit adds per 4.2
+                    # the nominal 2.4 GHz under this kind of load (the chip down-clocks)
                     "peak_sustained_measured": peak_ops * 1e-12 * 2.0 / 2.44,
                     "frac_of_sustained": fam_ach / (peak_ops * 1e-12 * 2.0 / 2.44),
+                    "whole_myers_stage": {"achieved": whole_ach, "frac": whole_ach / (peak_ops * 1e-12),
+                                          "note": "forward cells / all three passes (starts and traceback add no cells)"},
                     "largest_instantiation": {"kernel": kname, "achieved": achieved, "frac": achieved / (peak_ops * 1e-12),
                                               "traffic": traffic, "cells_per_launch": c / launches, "avg_launch_ms": ms / launches,
                                               "note": "runs concurrently with the other buckets' launches"},
-                    "hbm": {"algorithmic_bytes_per_step": batch.algorithmic_bytes, "achieved_GBs":
-                            batch.algorithmic_bytes / (all_ms / K * 1e-3) * 1e-9 if all_ms > 0 else None,
+                    "hbm": {"algorithmic_bytes_per_step": alg_bytes, "achieved_GBs":
+                            alg_bytes / (acc["all"] / K * 1e-3) * 1e-9 if alg_bytes and acc["all"] > 0 else None,
                             "peak_GBs": HBM_PEAK_GBS}}
         line = {
             "metric": "reads aligned/sec (whole node), MAM stage: Myers HW matching + MAM chaining",
-            "value": reads_all * K / elapsed, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "value": reads_all / elapsed, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 bit-vectors / int32 scores (Myers), f64 (chaining)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] synthetic form: ONT-cDNA-like reads (%s, err %.2f, ~%d bp), "
-                                   "%d reads/GPU/step, %d genes synthetic annotation" % (args.preset, P["err"], P["len_mean"], args.reads, args.genes),
-                       "reads_per_gpu_per_step": args.reads, "contexts_per_gpu": args.contexts, "pairs_per_step_per_gpu": batch.n_pairs,
-                       "cells_per_step_per_gpu": cells, "parallelism": "reads sharded, %d rank(s), no collective" % world},
-            "myers_gcups_forward": cells_all * K / (fwd_ms * 1e-3) * 1e-9 / 1.0 if fwd_ms > 0 else None,
-            "myers_gcups_all_passes": cells_all * K / (all_ms * 1e-3) * 1e-9 if all_ms > 0 else None,
-            "stage_ms_per_step": {"myers_forward": fwd_ms / K, "myers_starts": rev_ms / K, "myers_traceback": tb_ms / K,
-                                  "myers_total": all_ms / K, "mam_build": build_ms / K, "chain": chain_ms / K,
-                                  "chain_gather": gather_ms / K},
-            "outside_timed_region": {"host_plan_us_per_read": plan_s / len(insts) * 1e6, "host_planner": args.planner if args.contexts <= 1 else "python",
+            "config": {"workload": "BASELINE configs[2] synthetic form (SURVEY.md 8d C3): %d-gene / %d-chromosome GENCODE-shaped annotation with "
+                                   "overlapping genes (%d transcripts, %d segments), %d distinct %s reads per GPU (err %.2f, ~%d bp) as %d batches of %d, "
+                                   "device-resident, one step = one batch"
+                                   % (wkw["n_genes"], wkw["n_chr"], len(w.transcripts), len(w.ref_segment_sequences), args.reads * nb, args.preset,
+                                      P["err"], int(np.mean([rs.reads.size / max(len(rs), 1) for rs in sets])), nb, args.reads),
+                       "reads_per_gpu_per_step": args.reads, "distinct_batches_per_gpu": nb, "pairs_per_step_per_gpu": n_pairs,
+                       "candidates_per_step_per_gpu": n_cands, "cells_per_step_per_gpu": cells_step, "cells_per_read": cells_step / args.reads,
+                       "hw_queues": HW_QUEUES, "parallelism": "batches dealt over %d rank(s), no collective" % world},
+            "myers_gcups_forward": cells_all / (acc["fwd"] * 1e-3) * 1e-9 / world if acc["fwd"] > 0 else None,
+            "myers_gcups_all_passes": cells_all / (acc["all"] * 1e-3) * 1e-9 / world if acc["all"] > 0 else None,
+            "stage_ms_per_step": {"myers_forward": acc["fwd"] / K, "myers_starts": acc["rev"] / K, "myers_traceback": acc["tb"] / K,
+                                  "myers_total": acc["all"] / K, "mam_build": acc["build"] / K, "chain": acc["chain"] / K,
+                                  "chain_gather": acc["gather"] / K},
+            "outside_timed_region": {"stage_ms_first": stage_ms, "stage_ms": restage_ms,
+                                     "stage_note": "ultra_mam_stage_nams: H2D of NAM chains + reads, device plan, pair sort, work lists",
                                      "fetch_results_pcie_ms": fetch_s * 1e3, "python_tuples_ms": topy_s * 1e3,
-                                     "reads_per_s_incl_fetch": reads_all / world / (elapsed / K + fetch_s),
-                                     "chain_rows_fetched": int(res["chain_off"][-1])},
+                                     "world_s": world_s, "reads_s": reads_s, "host_index_s": index_s, "device_index_s": dindex_s},
+            "end_to_end": e2e,
             "forward_buckets": {"bucket%d_wmax%d" % k: {"cells_per_step": v[0] / v[2], "ms_per_step": v[1] / v[2],
                                                         "tcups": v[0] / v[1] * 1e-9 if v[1] > 0 else None}
                                 for k, v in sorted(class_ms.items())},
+            "micro": micro,
             "device": info, "parity_checked_instances": checked,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     for c in ctxs:
         c.close()
+    dix.close()
     if world > 1:
         dist.destroy_process_group()
 

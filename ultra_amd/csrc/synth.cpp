@@ -233,4 +233,93 @@ void synth_copy(const synth_out *o, uint8_t *reads, int64_t *read_off, int64_t *
 
 void synth_free(synth_out *o) { delete o; }
 
+// ---- (query, target, k) pairs of the Myers micro-benchmarks ------------------------------------
+// Targets are random sequences shared by `per_target` queries each; a query is either planted (a slice of its target
+// with the simulator's error mix at rate err) or an unrelated decoy (the reference aligns every small segment of a hit
+// gene, so most calls are decoys); k = (2 * min(m, n)) / 5 as classify_read_with_mams.py:312 passes it.
+//   q_model 0: length uniform in [q_a, q_b]; 1: log-normal (median q_a, sigma q_sigma) clipped to [q_min, q_max];
+//           2: q_a or q_b with equal probability
+//   t_len > 0: fixed target length; t_len <= 0: target = t_factor x the query's nominal length (one query per target)
+typedef struct synth_pair_params {
+    uint64_t seed;
+    int64_t n_pairs;
+    int32_t q_model, q_a, q_b, q_min, q_max;
+    double q_sigma;
+    int32_t t_len;
+    double t_factor;
+    int32_t per_target;
+    double err, planted;
+} synth_pair_params;
+
+typedef struct synth_pairs_out {
+    std::vector<uint8_t> arena;
+    std::vector<int64_t> q_off, t_off;
+    std::vector<int32_t> q_len, t_len, k;
+} synth_pairs_out;
+
+synth_pairs_out *synth_pairs(const synth_pair_params *p)
+{
+    static const char kBases[] = "ACGT";
+    if (!p || p->n_pairs < 0) return nullptr;
+    synth_pairs_out *o = new synth_pairs_out();
+    Rng rng(p->seed * 0x9E3779B97F4A7C15ull + 12345);
+    auto qlen = [&]() -> int64_t {
+        if (p->q_model == 0) return p->q_a + rng.below((int64_t)p->q_b - p->q_a + 1);
+        if (p->q_model == 1) {
+            int64_t v = (int64_t)(p->q_a * std::exp(p->q_sigma * rng.normal()));
+            return std::max<int64_t>(p->q_min, std::min<int64_t>(p->q_max, v));
+        }
+        return rng.uni() < 0.5 ? p->q_a : p->q_b;
+    };
+    std::vector<uint8_t> q;
+    int64_t done = 0;
+    while (done < p->n_pairs) {
+        int64_t m0 = qlen();
+        const int64_t n = p->t_len > 0 ? p->t_len : std::max<int64_t>(1, (int64_t)(p->t_factor * (double)m0));
+        const int64_t t_at = (int64_t)o->arena.size();
+        for (int64_t i = 0; i < n; i++) o->arena.push_back((uint8_t)kBases[rng.below(4)]);
+        const int64_t per = p->t_len > 0 ? std::max<int32_t>(1, p->per_target) : 1;
+        for (int64_t j = 0; j < per && done < p->n_pairs; j++, done++) {
+            if (j > 0) m0 = qlen();
+            q.clear();
+            if (rng.uni() < p->planted && m0 <= n) {
+                const int64_t a = rng.below(n - m0 + 1);
+                for (int64_t i = a; i < a + m0;) {
+                    const uint8_t c = o->arena[(size_t)(t_at + i)];
+                    if (rng.uni() < p->err) {
+                        const double r = rng.uni();
+                        if (r < 0.5) { int64_t dl = 1; while (rng.uni() >= 0.5) dl++; i += dl; continue; }
+                        else if (r < 0.8) q.push_back((uint8_t)kBases[rng.below(4)]);
+                        else { q.push_back(c); q.push_back((uint8_t)kBases[rng.below(4)]); while (rng.uni() >= 0.5) q.push_back((uint8_t)kBases[rng.below(4)]); }
+                    } else q.push_back(c);
+                    i++;
+                }
+                if (q.empty()) q.push_back((uint8_t)'A');
+            } else
+                for (int64_t i = 0; i < m0; i++) q.push_back((uint8_t)kBases[rng.below(4)]);
+            const int64_t m = (int64_t)q.size();
+            o->q_off.push_back((int64_t)o->arena.size()); o->q_len.push_back((int32_t)m);
+            o->arena.insert(o->arena.end(), q.begin(), q.end());
+            o->t_off.push_back(t_at); o->t_len.push_back((int32_t)n);
+            o->k.push_back((int32_t)((2 * std::min(m, n)) / 5));
+        }
+    }
+    return o;
+}
+
+void synth_pairs_sizes(const synth_pairs_out *o, int64_t *n_pairs, int64_t *arena_bytes)
+{
+    *n_pairs = (int64_t)o->k.size(); *arena_bytes = (int64_t)o->arena.size();
+}
+
+void synth_pairs_copy(const synth_pairs_out *o, uint8_t *arena, int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k)
+{
+    memcpy(arena, o->arena.data(), o->arena.size());
+    memcpy(q_off, o->q_off.data(), o->q_off.size() * 8); memcpy(q_len, o->q_len.data(), o->q_len.size() * 4);
+    memcpy(t_off, o->t_off.data(), o->t_off.size() * 8); memcpy(t_len, o->t_len.data(), o->t_len.size() * 4);
+    memcpy(k, o->k.data(), o->k.size() * 4);
+}
+
+void synth_pairs_free(synth_pairs_out *o) { delete o; }
+
 } // extern "C"

@@ -269,6 +269,47 @@ class _SynthParams(_C.Structure):
                 ("min_nam", _C.c_int32), ("n_threads", _C.c_int32)]
 
 
+class _PairParams(_C.Structure):
+    _fields_ = [("seed", _C.c_uint64), ("n_pairs", _C.c_int64), ("q_model", _C.c_int32), ("q_a", _C.c_int32), ("q_b", _C.c_int32),
+                ("q_min", _C.c_int32), ("q_max", _C.c_int32), ("q_sigma", _C.c_double), ("t_len", _C.c_int32),
+                ("t_factor", _C.c_double), ("per_target", _C.c_int32), ("err", _C.c_double), ("planted", _C.c_double)]
+
+
+# Myers micro-benchmarks of SURVEY.md section 8d: 50 % of the queries planted in their target at the config's error
+# rate, 50 % unrelated decoys, k = (2 * min(m, n)) // 5, seeds 1-4.  M-flank's target is not given there: a 2.5 kb read.
+MICRO = {
+    "M-small": dict(seed=1, n_pairs=1 << 20, q_model=0, q_a=9, q_b=64, t_len=1000, per_target=64),
+    "M-exon": dict(seed=2, n_pairs=1 << 20, q_model=1, q_a=130, q_sigma=0.9, q_min=9, q_max=2000, t_len=1000, per_target=64),
+    "M-flank": dict(seed=3, n_pairs=1 << 16, q_model=2, q_a=1000, q_b=2000, t_len=2500, per_target=8),
+    "M-contained": dict(seed=4, n_pairs=1 << 14, q_model=0, q_a=1000, q_b=10000, t_len=0, t_factor=1.25, per_target=1),
+}
+
+
+def make_micro_pairs(name, err=0.07, planted=0.5, n_pairs=None):
+    """(arena, q_off, q_len, t_off, t_len, k) of one micro-benchmark, generated by libultra_synth.so."""
+    spec = dict(MICRO[name])
+    if n_pairs is not None:
+        spec["n_pairs"] = int(n_pairs)
+    prm = _PairParams()
+    for f, _ in _PairParams._fields_:
+        setattr(prm, f, spec.get(f, 0))
+    prm.err, prm.planted = float(err), float(planted)
+    lib = _synth_lib()
+    h = lib.synth_pairs(_C.byref(prm))
+    if not h:
+        raise RuntimeError("synth_pairs failed")
+    try:
+        n, nb = _C.c_int64(), _C.c_int64()
+        lib.synth_pairs_sizes(h, _C.byref(n), _C.byref(nb))
+        arena = np.empty(max(nb.value, 1), np.uint8)
+        q_off, t_off = np.empty(n.value, np.int64), np.empty(n.value, np.int64)
+        q_len, t_len, k = np.empty(n.value, np.int32), np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+        lib.synth_pairs_copy(h, *[a.ctypes.data_as(_C.c_void_p) for a in (arena, q_off, q_len, t_off, t_len, k)])
+    finally:
+        lib.synth_pairs_free(h)
+    return arena[:nb.value], q_off, q_len, t_off, t_len, k
+
+
 def _synth_lib():
     global _SYNTH_LIB
     if _SYNTH_LIB is None:
@@ -284,6 +325,14 @@ def _synth_lib():
         lib.synth_copy.restype = None
         lib.synth_free.argtypes = [_C.c_void_p]
         lib.synth_free.restype = None
+        lib.synth_pairs.restype = _C.c_void_p
+        lib.synth_pairs.argtypes = [_C.POINTER(_PairParams)]
+        lib.synth_pairs_sizes.argtypes = [_C.c_void_p, _C.POINTER(_C.c_int64), _C.POINTER(_C.c_int64)]
+        lib.synth_pairs_sizes.restype = None
+        lib.synth_pairs_copy.argtypes = [_C.c_void_p] * 7
+        lib.synth_pairs_copy.restype = None
+        lib.synth_pairs_free.argtypes = [_C.c_void_p]
+        lib.synth_pairs_free.restype = None
         _SYNTH_LIB = lib
     return _SYNTH_LIB
 
