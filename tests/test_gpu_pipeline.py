@@ -1,0 +1,141 @@
+"""GPU: the batch pipeline (ultra_pipe) and the restaged align_single / pc front end.
+
+ultra_pipe must return, batch by batch and in submission order, exactly what the synchronous path returns, whatever the
+depth; align_single must not care how the reads are grouped into GPU batches."""
+import queue
+import struct
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return (a[0] == b[0] and struct.pack("d", float(a[1])) == struct.pack("d", float(b[1]))
+            and tuple(tuple(m) for m in a[2]) == tuple(tuple(m) for m in b[2]))
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_pipe_matches_synchronous_path(ctx, depth):
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import index as native
+    from ultra_amd import lib, synth
+    w = synth.make_world(seed=71, n_genes=120, n_chr=3, overlap_frac=0.3, exon_mean=12.0, max_exons=40)
+    idx = w.index()
+    flat = synth.FlatWorld(w)
+    rs = synth.make_reads_native(flat, 6000, seed=3, preset="ont_cdna", threads=4)
+    ix = native.NativeIndex(*idx)
+    dix = native.DeviceIndex(ix)
+    subs = [rs.slice(a, b) for a, b in ((0, 2500), (2500, 2600), (2600, 6000), (0, 1))]
+    want = []
+    try:
+        for s in subs:
+            ctx.mam_stage_nams(dix, s.nam_off, s.nam_part, s.nam_x, s.nam_y, s.reads, s.read_off)
+            ctx.mam_run(0.6)
+            want.append(stage.results_from_names(ctx.mam_fetch(want_names=True), np.diff(s.read_off).tolist()))
+        pipe = lib.Pipe(ix, 0, depth=depth)
+        try:
+            got = []
+            order = [0, 1, 2, 3, 2, 0]
+            sent = 0
+            while len(got) < len(order):
+                while sent < len(order) and pipe.pending() < depth:
+                    s = subs[order[sent]]
+                    pipe.submit(s.nam_off, s.nam_part, s.nam_x, s.nam_y, s.reads, s.read_off, 0.6)
+                    sent += 1
+                res = pipe.wait()
+                s = subs[order[len(got)]]
+                got.append(stage.results_from_names(res, np.diff(s.read_off).tolist()))
+                t = pipe.timing()
+                assert t["run_ms"] > 0 and t["cells"] > 0
+                pipe.release()
+            with pytest.raises(lib.UltraError):
+                pipe.wait()                         # nothing submitted
+        finally:
+            pipe.close()
+    finally:
+        dix.close(); ix.close()
+    for k, g in zip(order, got):
+        assert len(g) == len(want[k])
+        assert all(_same(a, b) for a, b in zip(g, want[k]))
+    for i in range(0, 2500, 97):                    # and the synchronous path equals the oracle
+        read, sol, _ = subs[0].instance(i)
+        assert _same(classify_port.classify(sol, *idx, read, None, 0.6), want[0][i])
+
+
+def _stub_downstream():
+    """Stand-ins for the stages behind the MAM stage (they stay the reference's code in a real installation): enough
+    structure to exercise every branch of the restaged loop, deterministic, and cheap."""
+    from ultra_amd import align
+
+    def find_exons(chr_id, mam_solution, ref_exon_sequences, ref_segment_sequences, ref_flank_sequences, splice_pairs):
+        exons = [(m.x, m.y, m.c, m.d, m.ref_chr_id) for m in mam_solution]
+        seq = "".join(ref_segment_sequences.get(align._array('L', [m.ref_chr_id, m.x, m.y]).tobytes(), "") for m in mam_solution)
+        pred = [(m.x, m.y) for m in mam_solution]
+        splices = [(a[1], b[0]) for a, b in zip(pred[:-1], pred[1:])]
+        return exons, seq, pred, splices, sum(m.d - m.c + 1 for m in mam_solution)
+
+    def classify(chr_id, splices, *rest):
+        return ("NO_SPLICE", "") if not splices else ("FSM" if len(splices) % 2 else "NIC_novel", "tr%d" % len(splices))
+
+    def exact_alignment(read_seq, ref_seq, exons_len):
+        n = min(len(read_seq), len(ref_seq))
+        score = 2 * sum(1 for a, b in zip(read_seq[:n], ref_seq[:n]) if a == b) - abs(len(read_seq) - len(ref_seq))
+        return read_seq[:n], ref_seq[:n], score
+
+    def sam_entry(*a, **kw):
+        return "\t".join(str(v) for v in a) + "\t" + str(sorted(kw.items())) + "\n"
+    return align.Downstream(find_exons, classify, exact_alignment, sam_entry)
+
+
+def test_align_single_is_independent_of_gpu_batching(ctx, tmp_path):
+    from ultra_amd import align, seed_wrapper, synth
+    world = synth.make_world(seed=77, n_genes=40, n_chr=2)
+    rng = np.random.RandomState(3)
+    sims = [synth.simulate_instance(world, rng, "ont_cdna") for _ in range(90)]
+    chr_ids = sorted({p[0] for p in world.part_seq})
+    data = (world.ref_segment_sequences, world.ref_flank_sequences, {}, {}, {c: {} for c in chr_ids}, {c: set() for c in chr_ids},
+            world.parts_to_segments, world.segment_to_gene, world.gene_to_small_segments, {c: 100000 for c in chr_ids},
+            {}, {str(c): c for c in chr_ids}, {c: "chr%d" % c for c in chr_ids})
+    state = align.AlignState(data, ctx=ctx, device=0)
+    records = []
+    for i, (read, sol, _) in enumerate(sims):
+        hits = [seed_wrapper.format_hit(m) for m in sol]
+        if i % 11 == 0:
+            hits = []                                                   # a read without seeds -> 'unaligned'
+        qual = None if i % 2 else "I" * len(read)
+        records.append(["read%d" % i, read + ("A" * 20 if i % 5 == 0 else ""), (qual + "I" * 20 if qual and i % 5 == 0 else qual), hits, []])
+    args = types.SimpleNamespace(outfolder=str(tmp_path), index="", reduce_read_ployA=8, max_intron=1200000, dropoff=0.95, max_loc=5,
+                                 min_acc=0.6, alignment_threshold=0.5, non_covered_cutoff=15, downstream=_stub_downstream(),
+                                 ultra_state=state)
+    try:
+        runs = []
+        for per_queue_batch, gpu_batch in ((1000, 65536), (7, 20), (1, 1)):
+            qin, qout, qcnt = queue.Queue(), queue.Queue(), queue.Queue()
+            for b in range(0, len(records), per_queue_batch):
+                qin.put([b // per_queue_batch + 1, records[b:b + per_queue_batch]])
+            qin.put(None)
+            args.gpu_batch_reads = gpu_batch
+            align.align_single(0, qin, qout, qcnt, args)
+            assert qin.get() is None                                    # the sentinel stays for other consumers
+            rows = []
+            n_lists = 0
+            while not qout.empty():
+                rows.extend(qout.get()); n_lists += 1
+            assert n_lists == (len(records) + per_queue_batch - 1) // per_queue_batch
+            runs.append((rows, qcnt.get()))
+    finally:
+        state.close()
+    assert runs[0][0] == runs[1][0] == runs[2][0]
+    assert runs[0][1][1:] == runs[1][1][1:] == runs[2][1][1:]
+    assert abs(runs[0][1][0] - runs[2][1][0]) < 1e-9
+    rows = runs[0][0]
+    assert len(rows) >= len(records)
+    assert sum("unaligned" in r for r in rows) >= len(records) // 11
+    fields = [r.split("\t") for r in rows]                              # read_id, seq, qual, ref, classification, ..., is_rc, is_secondary, mapq
+    primaries = [f for f in fields if f[4] != "unaligned" and f[10] == "False"]
+    assert sum(runs[0][1][1:]) == len(primaries) > len(records) // 2     # one classification count per aligned read
+    assert all(f[11] in ("0", "60") for f in primaries)

@@ -135,3 +135,308 @@ def mam_stage_batch(reads, locations, index, min_acc, ctx=None):
         seen[r].add(mam_solution)
         out[r].append((chr_id, is_rc, score, non_covered, value, mam_solution))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# align_single, restaged: the per-read loop of /root/reference/modules/align.py:392-560 as batch phases
+# ---------------------------------------------------------------------------------------------------------------
+# The signature, the queue protocol (batches of [batch_id, [(acc, seq, qual, hits, hits_rc), ...]], the None
+# sentinel put back for the other consumers, one list of SAM strings per input batch on output_sam_buffer, the
+# 8-entry classification list at the end) and every per-read decision are the reference's.  What changes is the
+# order of work: the reads of `args.gpu_batch_reads` queue batches are taken together through
+#     seeds -> instances + bounds (host)          -> ONE ultra_chain_nams_batch launch        (:429-453)
+#     location selection (host, :469-475)         -> ONE device-planned MAM stage             (:487-489)
+#     find_exons / classify_alignment2 (the reference's own modules, unchanged)                (:493-506)
+#     base-level alignment of every surviving location in one batch                            (:508)
+#     thresholds, primary / secondary, SAM rows (the reference's sam_output, unchanged)        (:510-551)
+# sam_output, classify_alignment2 and find_exons are not on the hot path and stay what they are (north_star): they
+# are taken from the uLTRA installation this module is dropped into (`modules.*`), or from `args.downstream`.
+import itertools
+import os
+import pickle
+from array import array as _array
+
+INDEX_FILES = ("ref_segment_sequences", "ref_flank_sequences", "splices_to_transcripts", "transcripts_to_splices",
+               "all_splice_pairs_annotations", "all_splice_sites_annotations", "parts_to_segments", "segment_to_gene",
+               "gene_to_small_segments", "max_intron_chr", "ref_exon_sequences", "chr_to_id", "id_to_chr")
+CLASS_OFFSET = {'FSM': 1, 'unaligned': 2, 'NO_SPLICE': 3, 'Insufficient_junction_coverage_unclassified': 4,
+                'ISM/NIC_known': 5, 'NIC_novel': 6, 'NNC': 7}
+
+
+def import_data(args):
+    """The 13 index dictionaries a worker reads (align.py:53-110), in the reference's order, from the pickles that
+    `uLTRA index` wrote (plain pickle protocol; written by the user's own indexing run)."""
+    folder = args.index if getattr(args, "index", "") else args.outfolder
+    out = []
+    for name in INDEX_FILES:
+        with open(os.path.join(folder, name + ".pickle"), "rb") as fh:
+            out.append(pickle.load(fh))
+    return tuple(out)
+
+
+def remove_read_polyA_ends(seq, qual, threshold_len, to_len):
+    """help_functions.py:41-73: homopolymer runs of A or T longer than threshold_len inside the last
+    min(len // 2, 100) bases are cut down to to_len bases (qualities: the first to_len of the run)."""
+    window = min(len(seq) // 2, 100)
+    head, tail = seq[:-window], seq[-window:]          # window == 0: seq[:-0] is '' and the tail the whole read, as there
+    out_seq, out_qual = [head], None
+    if qual is not None:
+        out_qual = [qual[:-window]]
+        tail_qual = qual[-window:]
+    pos = 0
+    for base, run in itertools.groupby(tail):
+        n = sum(1 for _ in run)
+        keep = to_len if (n > threshold_len and base in "AT") else n
+        out_seq.append(base * keep)
+        if out_qual is not None:
+            # the reference zips bases with qualities: a quality string shorter than the tail ends the walk early
+            out_qual.append(tail_qual[pos:pos + n][:keep])
+        pos += n
+    if qual is None:
+        return "".join(out_seq), None
+    if len(tail_qual) < len(tail):                       # zip() semantics of the reference, kept for odd inputs
+        return _polyA_zip_form(seq, qual, threshold_len, to_len, window)
+    return "".join(out_seq), "".join(out_qual)
+
+
+def _polyA_zip_form(seq, qual, threshold_len, to_len, window):
+    out_seq, out_qual = [seq[:-window]], [qual[:-window]]
+    pairs = list(zip(seq[-window:], qual[-window:]))
+    for base, grp in itertools.groupby(pairs, key=lambda p: p[0]):
+        quals = [q for _, q in grp]
+        keep = to_len if (len(quals) > threshold_len and base in "AT") else len(quals)
+        out_seq.append(base * keep)
+        out_qual.extend(quals[:keep])
+    return "".join(out_seq), "".join(out_qual)
+
+
+class Downstream(object):
+    """The stages behind the MAM stage that stay the reference's own code.  The default takes them from the uLTRA
+    installation (`modules.align.find_exons`, `modules.classify_alignment2.main`, `modules.align.get_exact_alignment`,
+    `modules.sam_output.main`); tests and the SIRV plumbing run pass their own."""
+
+    def __init__(self, find_exons=None, classify=None, exact_alignment=None, sam_entry=None, exact_alignment_batch=None):
+        if None in (find_exons, classify, sam_entry) or (exact_alignment is None and exact_alignment_batch is None):
+            try:
+                from modules import align as ref_align
+                from modules import classify_alignment2, sam_output
+            except ImportError as e:
+                raise ImportError("ultra_amd.align.align_single replaces uLTRA's MAM stage only: find_exons, classify_alignment2, "
+                                  "get_exact_alignment and sam_output are taken from the uLTRA installation (`modules.*`), which "
+                                  "is not importable here (%s); pass args.downstream = ultra_amd.align.Downstream(...) instead" % e)
+            find_exons = find_exons or ref_align.find_exons
+            classify = classify or classify_alignment2.main
+            sam_entry = sam_entry or sam_output.main
+            if exact_alignment is None and exact_alignment_batch is None:
+                exact_alignment = ref_align.get_exact_alignment
+        self.find_exons, self.classify, self.sam_entry = find_exons, classify, sam_entry
+        self.exact_alignment, self.exact_alignment_batch = exact_alignment, exact_alignment_batch
+
+    def align_all(self, jobs):
+        """jobs: [(read_seq, created_ref_seq, mam_sol_exons_length)] -> [(read_aln, ref_aln, alignment_score)]"""
+        if self.exact_alignment_batch is not None:
+            return self.exact_alignment_batch(jobs)
+        return [self.exact_alignment(*j) for j in jobs]
+
+
+class AlignState(object):
+    """What an align_single worker keeps between batches: index dictionaries, packed index on host and GPU, context."""
+
+    def __init__(self, data, ctx=None, device=None):
+        from . import index as native_index
+        from . import lib as _lib
+        (self.ref_segment_sequences, self.ref_flank_sequences, self.splices_to_transcripts, self.transcripts_to_splices,
+         self.all_splice_pairs_annotations, self.all_splice_sites_annotations, self.parts_to_segments, self.segment_to_gene,
+         self.gene_to_small_segments, self.max_intron_chr, self.ref_exon_sequences, self.chr_to_id, self.id_to_chr) = data
+        self.ctx = ctx or _lib.default_context()
+        self.native = native_index.NativeIndex(self.ref_segment_sequences, self.ref_flank_sequences, self.parts_to_segments,
+                                               self.segment_to_gene, self.gene_to_small_segments)
+        dev = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+        try:
+            self.dindex = native_index.DeviceIndex(self.native, dev)
+        except _lib.UltraError:
+            self.dindex = None          # index outside the device planner's envelope: batches are planned on the host
+        self._parts = {}
+        self.n_quadratic = self.n_nlogn = 0
+
+    def five(self):
+        return (self.ref_segment_sequences, self.ref_flank_sequences, self.parts_to_segments, self.segment_to_gene,
+                self.gene_to_small_segments)
+
+    def mam_stage(self, instances, min_acc):
+        """[(solution, read_seq)] -> [(non_covered_regions, value, mam_solution)]: one device-planned MAM stage."""
+        from . import index as native_index
+        from . import lib as _lib
+        import numpy as np
+        if not instances:
+            return []
+        if self.dindex is not None:
+            flat = native_index.flatten_instances(instances, self._parts)
+            try:
+                self.ctx.mam_stage_nams(self.dindex, *flat)
+                self.ctx.mam_run(min_acc)
+                res = self.ctx.mam_fetch(want_names=True)
+                return classify_read_with_mams.results_from_names(res, np.diff(flat[5]).tolist())
+            except _lib.UltraError as e:
+                if e.code != -4:        # only ULTRA_E_UNSUPPORTED means "plan this batch on the host"
+                    raise
+        return classify_read_with_mams.main_batch(instances, *self.five(), min_acc=min_acc, ctx=self.ctx, index=self.native)
+
+    def close(self):
+        if self.dindex is not None:
+            self.dindex.close()
+        self.native.close()
+
+
+def align_reads_batch(records, state, args, downstream):
+    """records: [(read_acc, seq, qual, hits, hits_rc)].  Returns ([SAM rows of read 0], [SAM rows of read 1], ...) and
+    the additions to the 8-entry classification list, exactly what the reference's loop (align.py:427-551) produces
+    for these reads."""
+    n = len(records)
+    counts = [0] * 8
+    mods = [remove_read_polyA_ends(seq, qual, args.reduce_read_ployA, 1) for _, seq, qual, _, _ in records]
+    # ---- phases 1-3: seeds -> instances -> NAM chaining -> location selection ----
+    locations = chain_reads_batch([(hits, hits_rc) for _, _, _, hits, hits_rc in records], state.max_intron_chr,
+                                  args.max_intron, args.dropoff, args.max_loc, ctx=state.ctx)
+    # ---- phase 4: one MAM stage over every (read, location) ----
+    instances, owner = [], []
+    rc_cache = {}
+    for r, locs in enumerate(locations):
+        for li, (chr_id, sol, score, is_rc) in enumerate(locs):
+            if is_rc:
+                if r not in rc_cache:
+                    rc_cache[r] = reverse_complement(mods[r][0])
+                instances.append((sol, rc_cache[r]))
+            else:
+                instances.append((sol, mods[r][0]))
+            owner.append((r, li))
+    mam_results = state.mam_stage(instances, args.min_acc)
+    by_read = [[] for _ in range(n)]
+    for (r, li), res in zip(owner, mam_results):
+        by_read[r].append(res)
+    # ---- phase 5: exon reconstruction + classification per surviving location; alignment jobs collected ----
+    pending = []        # per read: [(location fields..., job index)]
+    jobs = []
+    last_state = []     # per read: (read_seq, read_qual, is_rc) as the reference's loop variables stand after its last iteration
+    for r in range(n):
+        seq_mod, qual_mod = mods[r]
+        read_seq, read_qual, is_rc = None, None, False
+        seen, cand = set(), []
+        for (chr_id, mem_solution, chaining_score, loc_rc), (non_covered, mam_value, mam_solution) in zip(locations[r], by_read[r]):
+            is_rc = loc_rc
+            if is_rc:
+                read_seq = rc_cache[r]
+                read_qual = None if qual_mod is None else qual_mod[::-1]
+            else:
+                read_seq, read_qual = seq_mod, qual_mod
+            if mam_solution in seen:            # several optimal NAM chainings can lead to the same MAM solution (:493)
+                continue
+            seen.add(mam_solution)
+            exons_len = sum(m.y - m.x for m in mam_solution)
+            if not mam_value > 0:
+                continue
+            exons, created_ref_seq, predicted_exons, predicted_splices, covered = downstream.find_exons(
+                chr_id, mam_solution, state.ref_exon_sequences, state.ref_segment_sequences, state.ref_flank_sequences,
+                state.all_splice_pairs_annotations)
+            classification, transcript_id = downstream.classify(chr_id, predicted_splices, state.splices_to_transcripts,
+                                                                state.transcripts_to_splices, state.all_splice_pairs_annotations,
+                                                                state.all_splice_sites_annotations)
+            largest_intron = max([b.x - a.y for a, b in zip(mam_solution[:-1], mam_solution[1:])]) if len(mam_solution) > 1 else 0
+            if largest_intron > min(state.max_intron_chr[chr_id] + 20000, args.max_intron) and classification != 'FSM':
+                continue
+            jobs.append((read_seq, created_ref_seq, exons_len))
+            cand.append((len(jobs) - 1, read_seq, chr_id, classification, predicted_exons, transcript_id, is_rc, covered,
+                         non_covered, mam_solution))
+        pending.append(cand)
+        last_state.append((read_seq, read_qual, is_rc))
+    # ---- phase 6: base-level alignments, one batch ----
+    aligned = downstream.align_all(jobs)
+    # ---- phase 7: thresholds, primary / secondary, SAM rows ----
+    out = []
+    for r in range(n):
+        read_acc = records[r][0]
+        seq_mod, qual_mod = mods[r]
+        rows = []
+        if not locations[r]:
+            rows.append(downstream.sam_entry(read_acc, seq_mod, qual_mod, '*', 'unaligned', [], '*', '*', '*', False, False, 0))
+            out.append(rows)
+            continue
+        read_seq, read_qual, is_rc = last_state[r]
+        read_alignments = []
+        for (job, loc_seq, chr_id, classification, predicted_exons, transcript_id, loc_rc, covered, non_covered, mam_solution) in pending[r]:
+            read_aln, ref_aln, alignment_score = aligned[job]
+            if alignment_score < 2 * args.alignment_threshold * len(loc_seq) and classification != 'FSM':
+                continue
+            if len(non_covered) >= 3 and max(non_covered[1:-1]) > args.non_covered_cutoff:
+                classification = 'Insufficient_junction_coverage_unclassified'
+            read_alignments.append((alignment_score, mam_solution[0].x, mam_solution[-1].y, read_acc, chr_id, classification,
+                                    predicted_exons, read_aln, ref_aln, transcript_id, loc_rc, covered / float(len(loc_seq))))
+        if not read_alignments:
+            rows.append(downstream.sam_entry(read_acc, read_seq, read_qual, '*', 'unaligned', [], '*', '*', '*', is_rc, False, 0))
+            out.append(rows)
+            continue
+        ranked = sorted(read_alignments, key=lambda t: (-t[0], t[2] - t[1], t[5]))
+        for i, (score, g0, g1, acc, chr_id, classification, predicted_exons, read_aln, ref_aln, transcript_id, loc_rc, coverage) in enumerate(ranked):
+            if i == 0:
+                map_score = 0 if (len(ranked) > 1 and score == ranked[1][0]) else 60
+                counts[0] += coverage
+                counts[CLASS_OFFSET[classification]] += 1
+            else:
+                map_score = 0
+            # the reference hands every row the read as its LAST location iteration left it (:550), not the row's own strand
+            rows.append(downstream.sam_entry(acc, read_seq, read_qual, state.id_to_chr[chr_id], classification, predicted_exons, read_aln,
+                                             ref_aln, transcript_id, loc_rc, i > 0, map_score, aln_score=score))
+        out.append(rows)
+    return out, counts
+
+
+def align_single(process_id, input_queue, output_sam_buffer, classification_and_aln_cov, args):
+    """Drop-in for modules/align.py:392 (started by pc.py:81).  One worker drives one GPU: LOCAL_RANK, or
+    process_id modulo the number of GPUs.  args may carry, beyond the reference's fields: gpu_batch_reads (reads taken
+    through the phases together, default 65536), downstream (ultra_amd.align.Downstream), ultra_state (a prepared
+    AlignState, used by tests)."""
+    from . import lib as _lib
+    state = getattr(args, "ultra_state", None)
+    own_state = state is None
+    if own_state:
+        n_dev = max(1, _lib.load().ultra_device_count())
+        device = int(os.environ.get("LOCAL_RANK", process_id % n_dev))
+        state = AlignState(import_data(args), ctx=_lib.Context(device), device=device)
+    downstream = getattr(args, "downstream", None) or Downstream()
+    group_reads = int(getattr(args, "gpu_batch_reads", 65536))
+    log_path = os.path.join(args.outfolder, "uLTRA_batch_{0}.stderr".format(process_id))
+    warning_log_file = open(log_path, "w")
+    classification_list = [0, 0, 0, 0, 0, 0, 0, 0]
+    processed = 0
+    done = False
+    while not done:
+        group, n_reads = [], 0
+        while n_reads < group_reads:
+            if group and input_queue.empty():
+                break                                   # do not wait for more while reads are at hand
+            batch = input_queue.get()
+            if batch is None:
+                input_queue.put(batch)                  # the signal stays for the other consumers (:419-423)
+                done = True
+                break
+            group.append(batch)
+            n_reads += len(batch[1])
+        if not group:
+            continue
+        records = [tuple(b) for batch in group for b in batch[1]]
+        rows, counts = align_reads_batch(records, state, args, downstream)
+        for i in range(8):
+            classification_list[i] += counts[i]
+        at = 0
+        for batch in group:                             # one output list per input batch, as the reference puts them (:553)
+            k = len(batch[1])
+            output_sam_buffer.put([row for per_read in rows[at:at + k] for row in per_read])
+            at += k
+        processed += len(records)
+    classification_and_aln_cov.put(classification_list)
+    print('Process:', classification_list)
+    warning_log_file.close()
+    print("Number of reads processed by GPU worker {0}: {1}".format(process_id, processed))
+    if own_state:
+        state.close()
+        state.ctx.close()
