@@ -378,12 +378,18 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
         };
         auto block8 = [&](uint64_t chunk, int j0, auto tested) {
             constexpr bool TESTED = decltype(tested)::value;
+            constexpr bool FWD = MODE == MODE_FWD || MODE == MODE_FWD_EXACT;
             uint64_t eq[W], eqn[W];
+            // Forward pass: the eight bottom-row scores of the block stay in registers and only their minimum is
+            // tested against the threshold (one v_min3 per two columns); the end-column bookkeeping below runs for
+            // the few blocks in which some lane comes within reach of its best - not per column for every decoy.
+            int32_t sc[8];
             read_eq(eq, chunk, 0, !TESTED || j0 < n);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int j = j0 + u;
                 if (u < 7) read_eq(eqn, chunk, u + 1, !TESTED || j + 1 < n);
+                if (FWD) sc[u] = 0x3fffffff;
                 if (!TESTED || j < n) {
                     uint32_t hp = top_hp, hm = 0;
 #pragma unroll
@@ -396,18 +402,26 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
                         }
                     }
                     score += (int32_t)hp - (int32_t)hm;
-                    if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
-                        if (score <= lim) {
-                            if (score < best) { best = score; cnt = 0; lim = score; }
-                            if (cnt < out_cap) out[cnt] = j;
-                            cnt++;
-                        }
-                    } else if (MODE == MODE_REV) {
+                    if (FWD) sc[u] = score;
+                    else if (MODE == MODE_REV) {
                         if (score <= it.best) last = j;
                     }
                 }
 #pragma unroll
                 for (int b = 0; b < W; b++) eq[b] = eqn[b];
+            }
+            if (FWD) {
+                const int32_t bm = min(min(min(sc[0], sc[1]), min(sc[2], sc[3])), min(min(sc[4], sc[5]), min(sc[6], sc[7])));
+                if (bm <= lim) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (sc[u] <= lim) {
+                            if (sc[u] < best) { best = sc[u]; cnt = 0; lim = sc[u]; }
+                            if (cnt < out_cap) out[cnt] = j0 + u;
+                            cnt++;
+                        }
+                    }
+                }
             }
         };
         uint64_t ca = load8(it.t), cb = 0;
@@ -1080,13 +1094,19 @@ __global__ void k_reverse(const uint8_t *src, uint8_t *dst, int64_t n)
     if (i < n) dst[i] = src[n - 1 - i];
 }
 
-// packed[i] = (hit << 40) | nloc  so one scan yields both CSR offsets
-__global__ void k_pack(const int32_t *ed, const int32_t *nloc, uint64_t *packed, int32_t n, int slot_cap, int64_t *overflow)
+// packed[i] = (hit << 40) | nloc  so one scan yields both CSR offsets.  overflow[b] is set when a pair of register
+// bucket b (pairs [bucket_first[b], bucket_first[b + 1]) of the sorted order) has more end columns than first-pass slots.
+struct BucketFirst { int32_t first[6]; };
+__global__ void k_pack(const int32_t *ed, const int32_t *nloc, uint64_t *packed, int32_t n, int slot_cap, int64_t *overflow, BucketFirst bf)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         packed[i] = (ed[i] >= 0 ? (((uint64_t)1) << 40) : 0) | (uint64_t)(uint32_t)nloc[i];
-        if (nloc[i] > slot_cap) *overflow = 1; // rare; every writer stores the same value
+        if (nloc[i] > slot_cap) { // rare; every writer stores the same value
+            int b = 0;
+            while (b < 4 && i >= bf.first[b + 1]) b++;
+            overflow[b] = 1;
+        }
     }
 }
 
@@ -1635,12 +1655,23 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[4], s)); // all forward launches done
     // ---- CSR offsets ----
-    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bounds.as<int64_t>() + 63, 0, 8, s));
-    hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n, a.slot_cap, st.bounds.as<int64_t>() + 63);
+    int64_t *d_overflow = st.bounds.as<int64_t>() + 48; // one flag per register bucket
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_overflow, 0, kBuckets * 8, s));
+    {
+        BucketFirst bf;
+        for (int b = 0; b <= kBuckets; b++) bf.first[b] = n;
+        for (auto mc = st.classes.rbegin(); mc != st.classes.rend(); ++mc) {
+            const int b = bucket_of(class_of(64 * mc->G * mc->W));
+            for (int t = 0; t <= b; t++) bf.first[t] = std::min<int32_t>(bf.first[t], (int32_t)mc->pb);
+        }
+        bf.first[0] = 0;
+        for (int b = kBuckets - 1; b >= 1; b--) bf.first[b] = std::min(bf.first[b], bf.first[b + 1]);
+        hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, st.packed.as<uint64_t>(), n, a.slot_cap, d_overflow, bf);
+    }
     ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, st.packed.as<uint64_t>(), st.scanned.as<uint64_t>(), n, st.blocksum));
     hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, s, st.scanned.as<uint64_t>(), st.packed.as<uint64_t>(),
                        st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), n);
-    int64_t h_overflow = 0;
+    int64_t h_overflow[kBuckets] = {0, 0, 0, 0, 0};
     {
         // class boundaries (+ totals) to the host: one small copy, the only mid-batch synchronisation
         std::vector<int64_t> pos;
@@ -1654,7 +1685,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         std::vector<int64_t> hb((size_t)npz * 2);
         ultra_drain_guard drain_b(ctx); // pos / hb are copy endpoints
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb.data(), dout, npz * 16, hipMemcpyDeviceToHost, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_overflow, st.bounds.as<int64_t>() + 63, 8, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_overflow, d_overflow, kBuckets * 8, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         drain_b.dismiss();
         for (size_t c = 0; c < st.classes.size(); c++) {
@@ -1677,7 +1708,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     {
         ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
         for (int b = kBuckets - 1; b >= 0; b--) {
-            if (h_overflow)
+            if (h_overflow[b]) // only the buckets that have such a pair: an idle launch would still hold the bucket's lane
                 ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), st.buckets[b].n_fwd));
             MyArgs ab = a;
             ab.n_rr = 0;
