@@ -29,7 +29,7 @@ extern "C" {
 #define ULTRA_E_ARG (-1)         /* bad argument (null pointer, negative length, offsets out of range) */
 #define ULTRA_E_HIP (-2)         /* a HIP runtime call failed */
 #define ULTRA_E_CAPACITY (-3)    /* a caller-sized output is too small; the needed size is reported */
-#define ULTRA_E_UNSUPPORTED (-4) /* input outside the supported envelope (alphabet > 16 symbols, query > 32768) */
+#define ULTRA_E_UNSUPPORTED (-4) /* input outside the supported envelope (more than 36 distinct bytes in a batch, query > 32768) */
 #define ULTRA_E_NODEVICE (-5)    /* no usable gfx950 device */
 #define ULTRA_E_STATE (-6)       /* _run/_fetch called without a staged batch */
 

@@ -331,3 +331,49 @@ def test_restaging_pairs_invalidates_the_mam_batch(ctx):
         again = ctx.mam_fetch()
         for k in first:
             assert np.array_equal(np.asarray(first[k]), np.asarray(again[k])), k
+
+
+def test_soft_masked_and_iupac_batches(ctx):
+    """A batch with more than 16 distinct bytes - soft-masked (lower-case) segments, IUPAC codes and N in reads and
+    segments - goes through the whole stage, host-planned and device-planned, and equals the oracle: the reference
+    compares raw bytes and never upper-cases (uLTRA:43, create_augmented_gene.py:556)."""
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import index as native
+    from ultra_amd import synth
+    w = synth.make_world(seed=31, n_genes=40)
+    rng = np.random.RandomState(5)
+    codes = "NRYKMSWBVDHnrykmswbvdh"
+
+    def spoil(seq, p_mask, p_code):
+        s = list(seq)
+        if rng.rand() < p_mask and len(s) > 4:
+            a = int(rng.randint(0, len(s) - 2)); b = int(rng.randint(a + 1, len(s)))
+            s[a:b] = [c.lower() for c in s[a:b]]
+        for i in range(len(s)):
+            if rng.rand() < p_code:
+                s[i] = codes[int(rng.randint(0, len(codes)))]
+        return "".join(s)
+    for d in (w.ref_segment_sequences, w.ref_flank_sequences):
+        for k in list(d):
+            d[k] = spoil(d[k], 0.3, 0.004)
+    idx = w.index()
+    insts = synth.make_instances(w, 160, seed=9, preset="ont_cdna", flank_start_prob=0.3, flank_end_prob=0.3)
+    insts = [(spoil(read, 0.5, 0.003), sol, c) for read, sol, c in insts]
+    distinct = set("".join(r for r, _, _ in insts)) | set("".join(w.ref_segment_sequences.values()))
+    assert len(distinct) > 20
+    pairs = [(sol, read) for read, sol, _ in insts]
+    want = [classify_port.classify(sol, *idx, read, None, 0.6) for read, sol, _ in insts]
+    got = stage.main_batch(pairs, *idx, min_acc=0.6, ctx=ctx)
+    assert all(_same(a, b) for a, b in zip(want, got))
+    assert sum(1 for g in got if g[2]) > 100
+    ix = native.NativeIndex(*idx)
+    dix = native.DeviceIndex(ix)
+    try:
+        flat = native.flatten_instances(pairs)
+        ctx.mam_stage_nams(dix, *flat)
+        stage.run_staged(ctx, 0.6)
+        dev = stage.results_from_names(ctx.mam_fetch(want_names=True), np.diff(flat[5]).tolist())
+    finally:
+        dix.close(); ix.close()
+    assert all(_same(a, b) for a, b in zip(want, dev))

@@ -61,6 +61,22 @@ def test_alphabet_is_byte_exact(ctx):
     _check(ctx, helpers.make_pairs(rng, 800, (9, 200), (100, 600), kmode="ref", alpha="ACGTNacgtn"))
 
 
+IUPAC33 = "ACGTUNRYKMSWBVDH" + "acgtunrykmswbvdh" + "X"     # every byte the reference's reverse_complement knows
+
+
+@pytest.mark.parametrize("alpha", ["ACGTNacgtnRYKMSWBVDH", IUPAC33])
+def test_soft_masked_iupac_alphabets(ctx, alpha):
+    """More than 16 distinct bytes in a batch (soft-masked sequence + IUPAC codes): compared byte-exact and
+    case-sensitive like everything else (the reference never upper-cases), through every size class, the banded
+    traceback (up to 31 symbols) and the full-height one (beyond)."""
+    rng = np.random.RandomState(len(alpha))
+    got = _check(ctx, helpers.make_pairs(rng, 900, (5, 300), (100, 900), kmode="mixed", planted=0.8, alpha=alpha))
+    assert (got["ed"] >= 0).sum() > 300
+    _check(ctx, helpers.make_pairs(rng, 60, (300, 2600), (400, 3000), kmode="ref", planted=0.9, alpha=alpha, rates=(0.02, 0.1)))
+    _check(ctx, helpers.make_pairs(rng, 6, (2600, 9000), (3000, 9000), kmode="ref", planted=0.9, alpha=alpha, rates=(0.02, 0.1)))
+    _check(ctx, helpers.make_pairs(rng, 200, (9, 200), (100, 500), kmode="ref", planted=0.8, alpha=alpha), want_ops=True)
+
+
 def test_edit_scripts(ctx):
     rng = np.random.RandomState(8)
     _check(ctx, helpers.make_pairs(rng, 600, (9, 300), (100, 700), kmode="ref", planted=0.8), want_ops=True)
@@ -82,7 +98,7 @@ def test_empty_batch_and_bad_arguments(ctx):
     with pytest.raises(lib.UltraError):
         ctx.myers_hw_batch(np.zeros(4, np.uint8), [0], [0], [0], [4], [1])      # empty query
     with pytest.raises(lib.UltraError):
-        ctx.myers_hw_batch(np.arange(64, dtype=np.uint8), [0], [30], [30], [30], [5])  # > 16 distinct symbols
+        ctx.myers_hw_batch(np.arange(64, dtype=np.uint8), [0], [10], [10], [50], [5])  # > 36 distinct symbols
 
 
 def test_round_trip_property_at_scale(ctx):

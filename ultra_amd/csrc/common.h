@@ -115,7 +115,10 @@ struct MamState {
 constexpr int kAuxStreams = 7;
 constexpr int kLanes = kAuxStreams + 1;
 
-constexpr int kMaxSymbols = 16;
+// Distinct bytes of a batch (dense codes, byte-exact comparison).  The match table of a wavefront is S x words x 512 B of
+// LDS: up to 16 symbols the kernels keep their usual occupancy, beyond that (soft-masked sequence + IUPAC codes: 33 bytes)
+// they run with fewer wavefronts per CU; 36 is what still fits the 160 KB of a CU for the widest class (32768 rows).
+constexpr int kMaxSymbols = 36;
 constexpr size_t kArenaPad = 64;
 
 struct ultra_ctx {

@@ -696,7 +696,7 @@ extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, cons
                 if (dx->pool_mask[b >> 5] >> (b & 31) & 1u) { st.h_seen[b] = true; st.h_lut[b] = (uint8_t)(st.S < 255 ? st.S : 255); st.S++; }
         }
         st.pool_serial = 0; // the pool part below is (re)written
-        if (st.S > kMaxSymbols) return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage_nams: more than 16 distinct symbols in the index");
+        if (st.S > kMaxSymbols) return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage_nams: more than 36 distinct symbols in the index");
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.lut.p, st.h_lut, 256, hipMemcpyHostToDevice, s));
         ultra_launch_encode(s, dx->pool.as<uint8_t>(), P, st.lut.as<uint8_t>(), st.seq.as<uint8_t>(), st.rseq.as<uint8_t>(), (int64_t)kArenaPad, st.N);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
@@ -757,7 +757,7 @@ extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, cons
     bool lut_changed = false;
     for (int b = 0; b < 256; b++)
         if ((h_mask[b >> 5] >> (b & 31) & 1u) && !st.h_seen[b]) { st.h_seen[b] = true; st.h_lut[b] = (uint8_t)(st.S < 255 ? st.S : 255); st.S++; lut_changed = true; }
-    if (st.S > kMaxSymbols) { st.pool_serial = 0; return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage_nams: more than 16 distinct symbols in index + reads"); }
+    if (st.S > kMaxSymbols) { st.pool_serial = 0; return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage_nams: more than 36 distinct symbols in index + reads"); }
     if (st.S == 0) st.S = 1;
     if (lut_changed) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.lut.p, st.h_lut, 256, hipMemcpyHostToDevice, s));
     ultra_launch_encode(s, st.raw.as<uint8_t>(), read_bytes, st.lut.as<uint8_t>(), st.seq.as<uint8_t>(), st.rseq.as<uint8_t>(), (int64_t)kArenaPad + P, st.N);

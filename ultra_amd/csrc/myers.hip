@@ -1581,7 +1581,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
     int S = 0;
     for (int i = 0; i < 256; i++) { h_lut[i] = 0; if (h_mask[i >> 5] >> (i & 31) & 1u) h_lut[i] = (uint8_t)(S < 255 ? S : 255), S++; }
     if (S > kMaxSymbols)
-        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: more than 16 distinct symbols in the batch");
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: more than 36 distinct symbols in the batch");
     if (S == 0) S = 1;
     st.N = N; st.S = S;
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.seq.p, 0, kArenaPad, s));
@@ -1735,7 +1735,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     const int64_t n_hits = st.total_hit;
     int32_t h_band[2 * (kBandClasses + 1)]; // counts, then longest first location, per band class
     for (auto &v : h_band) v = 0;
-    const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0;
+    // the band kernels rebuild match vectors from 3 or 5 bit-planes of (code + 1): up to 31 symbols; beyond, full height
+    const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0 && st.S + 1 <= 32;
     a.nw_items = nullptr;
     bool forked = false;
     int32_t full_first[kNumSizeClasses + 1], full_edmax[kNumSizeClasses];
