@@ -182,6 +182,32 @@ int ultra_chain_nams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
                            int64_t *C, int32_t *trace, int64_t *value);
 
 /*
+ * Batched base-level alignment - the step right behind the MAM stage.  Replaces
+ *     help_functions.parasail_alignment(s1, s2, match_score=2, mismatch_penalty=-2, opening_penalty=3, gap_ext=1)
+ *         -> parasail.sg_trace_scan_16 / _32                    (modules/help_functions.py:204-226)
+ * as align.get_exact_alignment calls it per surviving location (modules/align.py:338-354): semi-global alignment of
+ * query (the read) against target (the reconstructed exon sequence), end gaps free in both sequences at both ends,
+ * affine gaps (a gap of length L costs gap_open + (L - 1) * gap_extend, penalties given as positive numbers),
+ * substitution matrix matrix_create("ACGT", match, mismatch): A, C, G, T match case-insensitively, every other pair
+ * of characters scores `mismatch`.
+ * out score[p]                 best score (int32 arithmetic: what the 16-bit scan kernel gives unless it saturates and
+ *                              what the 32-bit rerun gives then)
+ * out end_query / end_ref      0-based end cell (on the last row or the last column)
+ * ops / ops_off / n_ops        optional (all three or none): edit script over the WHOLE of both sequences - leading and
+ *                              trailing free gaps included, as help_functions.cigar_to_seq applies it (:217) - in
+ *                              FORWARD order into ops[ops_off[p] ..), codes 0 '=', 1 'I' (query base against a gap),
+ *                              2 'D', 3 'X'; every slot must hold q_len + t_len codes
+ * parasail itself is absent from the build image: the score is mathematically defined; the choice among co-optimal
+ * end cells and paths follows oracle/affine_port.c (last row before last column, strictly better replaces; diagonal
+ * before 'I' before 'D'; extending a gap wins a tie against opening one) and is PARITY UNPINNED against parasail.
+ */
+int ultra_sg_affine_batch(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,
+                          const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
+                          int32_t match, int32_t mismatch, int32_t gap_open, int32_t gap_extend,
+                          int32_t *score, int32_t *end_query, int32_t *end_ref,
+                          uint8_t *ops, const int64_t *ops_off, int32_t *n_ops);
+
+/*
  * The whole MAM stage of a batch of (read, location) instances in one call, results identical to
  *     classify_read_with_mams.main(solution, ..., read_seq, warning_log_file, min_acc)
  *         -> (non_covered_regions, value, mam_solution)          (modules/classify_read_with_mams.py:406-594)

@@ -184,3 +184,21 @@ def nam_nlogn(c, d):
     if rc != 0:
         raise RuntimeError("oracle nam_nlogn: reference BUG path")
     return C.tolist(), tr.tolist()
+
+
+# ---- base-level affine-gap alignment -------------------------------------
+def sg_affine(query, target, match=2, mismatch=-2, gap_open=3, gap_extend=1, want_path=True):
+    """Oracle for help_functions.parasail_alignment (sg_trace_scan): dict(score, end_query, end_ref, cigar, ops)."""
+    q = query.encode() if isinstance(query, str) else bytes(query)
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    m, n = len(q), len(t)
+    ops = np.zeros(m + n + 2, np.uint8)
+    score, eq, et, nops = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    L = lib()
+    L.oracle_sg_affine.restype = C.c_int
+    rc = L.oracle_sg_affine(q, m, t, n, match, mismatch, gap_open, gap_extend, C.byref(score), C.byref(eq), C.byref(et),
+                            _p(ops, C.c_uint8) if want_path else None, len(ops), C.byref(nops))
+    if rc != 0:
+        raise RuntimeError("oracle sg_affine failed rc=%d" % rc)
+    o = ops[:nops.value].tolist()
+    return {"score": score.value, "end_query": eq.value, "end_ref": et.value, "ops": o, "cigar": ops_to_cigar(o) if want_path else None}

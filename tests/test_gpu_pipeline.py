@@ -137,5 +137,5 @@ def test_align_single_is_independent_of_gpu_batching(ctx, tmp_path):
     assert sum("unaligned" in r for r in rows) >= len(records) // 11
     fields = [r.split("\t") for r in rows]                              # read_id, seq, qual, ref, classification, ..., is_rc, is_secondary, mapq
     primaries = [f for f in fields if f[4] != "unaligned" and f[10] == "False"]
-    assert sum(runs[0][1][1:]) == len(primaries) > len(records) // 2     # one classification count per aligned read
+    assert sum(runs[0][1][1:]) == len(primaries) > len(records) // 4     # one classification count per aligned read
     assert all(f[11] in ("0", "60") for f in primaries)

@@ -210,13 +210,97 @@ def _polyA_zip_form(seq, qual, threshold_len, to_len, window):
     return "".join(out_seq), "".join(out_qual)
 
 
+_OP_CHARS = "=IDX"
+
+
+def _script_to_alignment(ops, query, ref):
+    """Gapped strings of an edit script (codes 0 '=', 1 'I', 2 'D', 3 'X') the way help_functions.cigar_to_seq
+    (:136-179) lays them out: 'I' puts a query base against '-', 'D' a reference base against '-'."""
+    q_aln, r_aln, qi, ri = [], [], 0, 0
+    for op in ops:
+        if op == 1:
+            q_aln.append(query[qi]); r_aln.append('-'); qi += 1
+        elif op == 2:
+            q_aln.append('-'); r_aln.append(ref[ri]); ri += 1
+        else:
+            q_aln.append(query[qi]); r_aln.append(ref[ri]); qi += 1; ri += 1
+    return "".join(q_aln), "".join(r_aln)
+
+
+def _takes_edlib_route(read_seq, created_ref_seq, mam_sol_exons_length):
+    # align.py:341: very long sequences go through edlib's HW mode instead of parasail
+    return len(created_ref_seq) > 20000 or len(read_seq) > 20000 or (1000 < len(read_seq) < mam_sol_exons_length / 10)
+
+
+def get_exact_alignment_batch(jobs, ctx=None):
+    """jobs: [(read_seq, created_ref_seq, mam_sol_exons_length)] -> [(read_aln, ref_aln, alignment_score)], what
+    align.get_exact_alignment (align.py:338-354) returns for each, with parasail.sg_trace_scan replaced by ONE
+    ultra_sg_affine_batch launch and edlib (the > 20 kb route, help_functions.py:181-192) by ultra_myers_hw_batch."""
+    import numpy as np
+    from . import lib as _lib
+    ctx = ctx or _lib.default_context()
+    out = [None] * len(jobs)
+    routes = [_takes_edlib_route(*j) for j in jobs]
+    for want_edlib in (False, True):
+        sel = [i for i, r in enumerate(routes) if r == want_edlib]
+        if not sel:
+            continue
+        chunks, size, qo, ql, to, tl = [], 0, [], [], [], []
+        for i in sel:
+            for seq, offs, lens in ((jobs[i][0], qo, ql), (jobs[i][1], to, tl)):
+                b = seq.encode()
+                offs.append(size); lens.append(len(b)); chunks.append(b); size += len(b)
+        arena = np.frombuffer(b"".join(chunks) or b"\0", np.uint8)
+        if not want_edlib:
+            res = ctx.sg_affine_batch(arena, qo, ql, to, tl, 2, -2, 3, 1, want_ops=True)
+            for k, i in enumerate(sel):
+                o = int(res["ops_off"][k])
+                ops = res["ops"][o:o + int(res["n_ops"][k])].tolist()
+                read_aln, ref_aln = _script_to_alignment(ops, jobs[i][0], jobs[i][1])
+                out[i] = (read_aln, ref_aln, int(res["score"][k]))
+        else:
+            res = ctx.myers_hw_batch(arena, qo, ql, to, tl, [-1] * len(sel), want_ops=True)
+            for k, i in enumerate(sel):
+                read_seq, ref_seq = jobs[i][0], jobs[i][1]
+                lo = int(res["loc_off"][k])
+                start, stop = int(res["loc_start"][lo]), int(res["loc_end"][lo])
+                o = int(res["ops_off"][k])
+                ops = res["ops"][o:o + int(res["n_ops"][k])][::-1].tolist()
+                # help_functions.edlib_alignment (:181-192) hands cigar_to_seq ref_seq[start:stop] - one base short of the
+                # location - and pads with ref_seq[stop:]: string slicing forgives the missing base, so does this
+                piece = ref_seq[start:stop]
+                q_aln, r_aln, qi, ri = [], [], 0, 0
+                for op in ops:
+                    if op == 1:
+                        q_aln.append(read_seq[qi:qi + 1]); r_aln.append('-'); qi += 1
+                    elif op == 2:
+                        q_aln.append('-'); r_aln.append(piece[ri:ri + 1]); ri += 1
+                    else:
+                        q_aln.append(read_seq[qi:qi + 1]); r_aln.append(piece[ri:ri + 1]); qi += 1; ri += 1
+                read_aln = "-" * start + "".join(q_aln) + "-" * (len(ref_seq) - stop - 1)
+                ref_aln = ref_seq[:start] + "".join(r_aln) + ref_seq[stop:]
+                if len(read_aln) != len(ref_aln):
+                    raise AssertionError("edlib route: alignment strings differ in length (help_functions.py:191)")
+                match_score = sum(2 for a, b in zip(read_aln, ref_aln) if a == b)
+                out[i] = (read_aln, ref_aln, match_score - 2 * int(res["ed"][k]))
+    return out
+
+
+def get_exact_alignment(read_seq, created_ref_seq, mam_sol_exons_length, ctx=None):
+    """align.py:338 for one pair (one GPU batch per call: use get_exact_alignment_batch for throughput)."""
+    return get_exact_alignment_batch([(read_seq, created_ref_seq, mam_sol_exons_length)], ctx=ctx)[0]
+
+
 class Downstream(object):
     """The stages behind the MAM stage that stay the reference's own code.  The default takes them from the uLTRA
     installation (`modules.align.find_exons`, `modules.classify_alignment2.main`, `modules.align.get_exact_alignment`,
-    `modules.sam_output.main`); tests and the SIRV plumbing run pass their own."""
+    `modules.sam_output.main`); tests and the SIRV plumbing run pass their own.  The base-level alignment
+    (get_exact_alignment) defaults to this package's GPU batch (get_exact_alignment_batch)."""
 
     def __init__(self, find_exons=None, classify=None, exact_alignment=None, sam_entry=None, exact_alignment_batch=None):
-        if None in (find_exons, classify, sam_entry) or (exact_alignment is None and exact_alignment_batch is None):
+        if exact_alignment is None and exact_alignment_batch is None:
+            exact_alignment_batch = get_exact_alignment_batch      # row f2: base-level alignment on the GPU, one batch
+        if None in (find_exons, classify, sam_entry):
             try:
                 from modules import align as ref_align
                 from modules import classify_alignment2, sam_output
@@ -227,8 +311,6 @@ class Downstream(object):
             find_exons = find_exons or ref_align.find_exons
             classify = classify or classify_alignment2.main
             sam_entry = sam_entry or sam_output.main
-            if exact_alignment is None and exact_alignment_batch is None:
-                exact_alignment = ref_align.get_exact_alignment
         self.find_exons, self.classify, self.sam_entry = find_exons, classify, sam_entry
         self.exact_alignment, self.exact_alignment_batch = exact_alignment, exact_alignment_batch
 

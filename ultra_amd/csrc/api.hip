@@ -69,6 +69,7 @@ void ultra_ctx_destroy(ultra_ctx *ctx)
     ultra_myers_free(ctx);
     ultra_chain_free(ctx);
     ultra_mam_free(ctx);
+    ultra_affine_free(ctx);
     for (int i = 0; i < kAuxStreams; i++) {
         if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
         if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);

@@ -109,6 +109,10 @@ struct MamState {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
+struct AffineState {
+    DevBuf seq, qoff, toff, qlen, tlen, troff, bdoff, tr, bd, score, endq, endt, ops, opsoff, nops;
+};
+
 // Launch lanes = HIP streams the independent launches of a pass are dealt over.  Streams beyond the process's
 // hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise before the first HIP call) share a
 // queue and serialise, so the default lane count follows that variable (ultra_ctx_create).
@@ -139,6 +143,7 @@ struct ultra_ctx {
     MyersState my;
     ChainState ch;
     MamState mam;
+    AffineState aff;
 };
 
 #define ULTRA_HIP_CHECK(ctx, call)                                                                      \
@@ -225,3 +230,4 @@ hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int
 void ultra_myers_free(ultra_ctx *ctx);
 void ultra_chain_free(ultra_ctx *ctx);
 void ultra_mam_free(ultra_ctx *ctx);
+void ultra_affine_free(ultra_ctx *ctx);

@@ -28,7 +28,7 @@ EXPORTS = [
     "ultra_dindex_create", "ultra_dindex_destroy", "ultra_dindex_last_error", "ultra_mam_stage_nams", "ultra_mam_counts",
     "ultra_mam_fetch_plan",
     "ultra_pipe_create", "ultra_pipe_destroy", "ultra_pipe_last_error", "ultra_pipe_submit", "ultra_pipe_pending",
-    "ultra_pipe_wait", "ultra_pipe_release", "ultra_pipe_timing",
+    "ultra_pipe_wait", "ultra_pipe_release", "ultra_pipe_timing", "ultra_sg_affine_batch",
 ]
 
 
@@ -144,6 +144,8 @@ def load():
     lib.ultra_mam_counts.argtypes = [vp, i32p, i32p, i32p]
     lib.ultra_mam_fetch_plan.argtypes = [vp, i64p, i32p, i64p, i64p, u8p, i32p, i32p, i32p, i32p, i32p, i32p, i32p,
                                          i64p, i32p, i64p, i32p, i32p]
+    lib.ultra_sg_affine_batch.argtypes = [vp, u8p, C.c_size_t, C.c_int32, i64p, i32p, i64p, i32p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, i32p, i32p, i32p, u8p, i64p, i32p]
     lib.ultra_pipe_create.argtypes = [C.c_int, C.POINTER(Cfg), vp, C.c_int32, C.POINTER(vp)]
     lib.ultra_pipe_destroy.argtypes = [vp]
     lib.ultra_pipe_destroy.restype = None
@@ -411,6 +413,30 @@ class Context(object):
         self._check(self.lib.ultra_mam_fetch(self._h, C.byref(out)))
         r["value"], r["n_mam"] = r["value"][:ni], r["n_mam"][:ni]
         return r
+
+    # ---- base-level alignment ------------------------------------------------------------------
+    def sg_affine_batch(self, arena, q_off, q_len, t_off, t_len, match=2, mismatch=-2, gap_open=3, gap_extend=1, want_ops=True):
+        """Semi-global affine-gap alignment of a batch of pairs (ultra_sg_affine_batch).  Returns dict(score, end_query,
+        end_ref[, ops, ops_off, n_ops]); the edit script of pair p is ops[ops_off[p] : ops_off[p] + n_ops[p]], forward."""
+        arena = _arr(arena, np.uint8)
+        q_off, t_off = _arr(q_off, np.int64), _arr(t_off, np.int64)
+        q_len, t_len = _arr(q_len, np.int32), _arr(t_len, np.int32)
+        n = len(q_len)
+        score = np.zeros(max(n, 1), np.int32); eq = np.zeros(max(n, 1), np.int32); et = np.zeros(max(n, 1), np.int32)
+        ops = ops_off = n_ops = None
+        if want_ops:
+            ops_off = np.zeros(n + 1, np.int64)
+            np.cumsum(q_len.astype(np.int64) + t_len.astype(np.int64), out=ops_off[1:])
+            ops = np.zeros(max(int(ops_off[-1]), 1), np.uint8); n_ops = np.zeros(max(n, 1), np.int32)
+        self._check(self.lib.ultra_sg_affine_batch(self._h, _ptr(arena, C.c_uint8), arena.size, n, _ptr(q_off, C.c_int64),
+                                                   _ptr(q_len, C.c_int32), _ptr(t_off, C.c_int64), _ptr(t_len, C.c_int32),
+                                                   int(match), int(mismatch), int(gap_open), int(gap_extend),
+                                                   _ptr(score, C.c_int32), _ptr(eq, C.c_int32), _ptr(et, C.c_int32),
+                                                   _ptr(ops, C.c_uint8), _ptr(ops_off, C.c_int64), _ptr(n_ops, C.c_int32)))
+        out = {"score": score[:n], "end_query": eq[:n], "end_ref": et[:n]}
+        if want_ops:
+            out.update(ops=ops, ops_off=ops_off, n_ops=n_ops[:n])
+        return out
 
     # ---- chaining ----------------------------------------------------------------------------
     def chain_mams_batch(self, inst_off, x, y, c, d, val, solver=0, overlap_small=-1, overlap_large=-1, noalloc=False):
