@@ -198,7 +198,7 @@ int ultra_chain_nams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
  *                              FORWARD order into ops[ops_off[p] ..), codes 0 '=', 1 'I' (query base against a gap),
  *                              2 'D', 3 'X'; every slot must hold q_len + t_len codes
  * parasail itself is absent from the build image: the score is mathematically defined; the choice among co-optimal
- * end cells and paths follows oracle/affine_port.c (last row before last column, strictly better replaces; diagonal
+ * end cells and paths is this library's own (last row before last column, strictly better replaces; diagonal
  * before 'I' before 'D'; extending a gap wins a tie against opening one) and is PARITY UNPINNED against parasail.
  */
 int ultra_sg_affine_batch(ultra_ctx *ctx, const uint8_t *arena, size_t arena_len, int32_t n_pairs,

@@ -5,7 +5,7 @@
 // as align.get_exact_alignment calls it               /root/reference/modules/align.py:338-354.
 // parasail is a third-party C library that is absent here: the recurrences are Gotoh's, the conventions (free end gaps
 // in both sequences, gap of length L = open + (L - 1) * extend, matrix_create("ACGT", match, mismatch)) parasail's
-// published ones, the tie rules those of oracle/affine_port.c (parity unpinned against parasail itself).
+// published ones; the tie rules are this file's own and stated in include/ultra_hip.h (parity unpinned against parasail itself).
 //
 // Fill: one wavefront per pair, 64 query rows per strip, skewed schedule - at step t lane l computes the cell
 // (row 64 s + l, column t - l), its upper neighbours come from lane l - 1 (one cross-lane move per value and step),
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64) k_affine_fill(AffArgs a)
         }
         __syncthreads(); // the boundary row written by lane 63 is read by every lane of the next strip
     }
-    // end cell: last row left to right, then last column top to bottom, strictly better replaces (oracle/affine_port.c)
+    // end cell: last row left to right, then last column top to bottom, strictly better replaces (include/ultra_hip.h)
     int32_t vr = best_row, jr = best_j;
     {
         const int src = (m - 1) & 63;

@@ -385,7 +385,7 @@ class ReadSet(object):
         return r
 
     def instance(self, i):
-        """(read_seq, solution, chr_id) of read i in the form simulate_instance returns (for the oracle)."""
+        """(read_seq, solution, chr_id) of read i in the form simulate_instance returns (Python objects, for per-read checks)."""
         r0, r1, n0, n1 = int(self.read_off[i]), int(self.read_off[i + 1]), int(self.nam_off[i]), int(self.nam_off[i + 1])
         sol = []
         for j, u in enumerate(range(n0, n1)):
