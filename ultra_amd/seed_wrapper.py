@@ -19,30 +19,40 @@ def _open(path):
     return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
 
 
+def _blocks(fh):
+    """(header or None, hit lines) per header-delimited block of a seed file; None = lines before any header."""
+    header, lines = None, []
+    for raw in fh:
+        line = raw.decode('utf-8')
+        if line[0] == '>':
+            yield header, lines
+            header, lines = line[1:].strip(), []
+        else:
+            lines.append(line)
+    yield header, lines
+
+
 def read_seeds(seeds):
-    """Yields (acc, hits, acc_rev, hits_rc) per read, hits = the raw hit lines (seed_wrapper.py:139-179).
-    As in the reference a pair is only emitted once both its forward and its "Reverse" header were seen, and
-    lines before the first header count as forward hits of the first read.  Plain text is accepted besides gzip."""
-    curr_acc, curr_acc_rev, is_rc = '', '', False
-    hits, hits_rc = [], []
+    """Yields (acc, hits, acc_rev, hits_rc) per read, hits = the raw hit lines: the stream the reference's
+    read_seeds produces (seed_wrapper.py:139-179).  A read is handed over at the first header that follows both its
+    forward and its "Reverse" block (or at the end of the file); until then blocks accumulate, so a repeated forward
+    header only renames the pending read, and hit lines before the first header belong to the first read's forward
+    strand.  Plain text is accepted besides gzip."""
+    pending = {"fw": '', "rc": ''}
+    hits = {"fw": [], "rc": []}
     with _open(seeds) as fh:
-        for raw in fh:
-            line = raw.decode('utf-8')
-            if line[0] == '>':
-                if curr_acc and curr_acc_rev:
-                    yield curr_acc, hits, curr_acc_rev, hits_rc
-                    curr_acc, curr_acc_rev, is_rc = '', '', False
-                    hits, hits_rc = [], []
-                if 'Reverse' in line:
-                    curr_acc_rev, is_rc = line[1:].strip(), True
-                else:
-                    curr_acc, is_rc = line[1:].strip(), False
-            elif is_rc:
-                hits_rc.append(line)
-            else:
-                hits.append(line)
-    if curr_acc and curr_acc_rev:
-        yield curr_acc, hits, curr_acc_rev, hits_rc
+        for header, lines in _blocks(fh):
+            if header is None:
+                hits["fw"] += lines
+                continue
+            if pending["fw"] and pending["rc"]:
+                yield pending["fw"], hits["fw"], pending["rc"], hits["rc"]
+                pending, hits = {"fw": '', "rc": ''}, {"fw": [], "rc": []}
+            strand = "rc" if 'Reverse' in header else "fw"
+            pending[strand] = header
+            hits[strand] += lines
+    if pending["fw"] and pending["rc"]:
+        yield pending["fw"], hits["fw"], pending["rc"], hits["rc"]
 
 
 def format_hit(mem):
