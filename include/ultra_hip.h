@@ -311,8 +311,11 @@ void ultra_index_destroy(ultra_index *idx);
  * (mam_id = str(pack('LLL', ident_chr, e_start, e_stop)) + label, or "flank_<start>_<stop>" + label), and the
  * forward-pass cell count of the batch.  A candidate whose segment has no gene / no sequence in the index is the
  * reference's KeyError: ULTRA_E_ARG, text from ultra_plan_last_error() (thread-local).
- * Where the reference's order depends on the iteration order of a Python set (equal segment starts within one
- * instance - does not occur for canonical segments) the order here is (start, stop, chromosome).
+ * Where the reference's order depends on the iteration order of a Python set - hit segments of one instance that
+ * start at the same coordinate, classify_read_with_mams.py:180-253 - both planners reproduce that order (CPython's
+ * tuple hash and set probing restated in csrc/pyset.h).  ultra_pyset_order exposes the restatement so that it can be
+ * checked against an interpreter: `triples` = n pairwise distinct (chr, start, stop) in insertion order, order[k] =
+ * index of the k-th tuple a Python set of them iterates.  Host only, no GPU.
  */
 typedef struct ultra_plan ultra_plan;
 typedef struct ultra_plan_request {
@@ -326,6 +329,7 @@ const ultra_mam_input *ultra_plan_input(const ultra_plan *plan);
 int ultra_plan_cands(const ultra_plan *plan, const int32_t **chr, const int32_t **ident_chr, double *cells);
 void ultra_plan_destroy(ultra_plan *plan);
 const char *ultra_plan_last_error(void);
+int ultra_pyset_order(const int64_t *triples, int32_t n, int32_t *order);
 
 /*
  * The same enumeration ON THE DEVICE.  ultra_dindex_create flattens the host index once more and uploads it (segment

@@ -134,3 +134,78 @@ def mam_rows(sol):
     """Canonical comparable form of a MAM tuple list (val as IEEE-754 hex)."""
     return [[int(m.x), int(m.y), int(m.c), int(m.d), float(m.val).hex(), int(m.j), int(m.min_segment_length),
              str(m.mam_id), int(m.ref_chr_id)] for m in sol]
+
+
+# ---- transcript of downstream calls (tests/golden/make_align_single_golden.py and its replay) ----
+def digest(obj):
+    """Stable digest of call arguments (floats by their bits, tuples as lists, sets sorted)."""
+    import hashlib
+    import json
+
+    def norm(v):
+        if isinstance(v, float):
+            return v.hex()
+        if isinstance(v, (list, tuple)):
+            return [norm(x) for x in v]
+        if isinstance(v, (set, frozenset)):
+            return sorted(norm(x) for x in v)
+        if isinstance(v, dict):
+            return sorted([norm(k), norm(x)] for k, x in v.items())
+        if isinstance(v, np.integer):
+            return int(v)
+        return v
+    return hashlib.sha1(json.dumps(norm(obj), sort_keys=True).encode()).hexdigest()[:20]
+
+
+def jsonable(v):
+    if isinstance(v, float):
+        return {"f": v.hex()}
+    if isinstance(v, tuple):
+        return {"t": [jsonable(x) for x in v]}
+    if isinstance(v, list):
+        return [jsonable(x) for x in v]
+    if isinstance(v, (set, frozenset)):
+        return {"s": sorted(jsonable(x) for x in v)}
+    if isinstance(v, np.integer):
+        return int(v)
+    return v
+
+
+def unjsonable(v):
+    if isinstance(v, dict):
+        if "f" in v:
+            return float.fromhex(v["f"])
+        if "t" in v:
+            return tuple(unjsonable(x) for x in v["t"])
+        return set(unjsonable(x) for x in v["s"])
+    if isinstance(v, list):
+        return [unjsonable(x) for x in v]
+    return v
+
+
+def mam_key(sol):
+    return [[m.x, m.y, m.c, m.d, m.val, m.j, m.min_segment_length, str(m.mam_id), m.ref_chr_id] for m in sol]
+
+
+def simulate_transcript_reads(exons, refs, rng, n):
+    by_tr = {}
+    for e in exons:
+        by_tr.setdefault((e.seqid, e.transcript_id), []).append((e.start - 1, e.stop))
+    keys = sorted(by_tr)
+    reads = []
+    for i in range(n):
+        seqid, tid = keys[int(rng.randint(len(keys)))]
+        spans = sorted(by_tr[(seqid, tid)])
+        rna = "".join(refs[seqid][a:b] for a, b in spans).upper()
+        ln = int(rng.randint(250, 1100))
+        a = int(rng.randint(0, max(1, len(rna) - ln)))
+        seq = mutate(rng, rna[a:a + ln], float(rng.choice([0.0, 0.03, 0.08, 0.14])))
+        if i % 9 == 4:
+            seq = rand_seq(rng, int(rng.randint(200, 500)))             # junk: unaligned
+        if i % 4 == 1:
+            seq = seq + "A" * int(rng.randint(12, 40))                           # poly-A tail
+        if i % 2:
+            seq = seq.translate(str.maketrans('ACGT', 'TGCA'))[::-1]
+        qual = "".join(chr(33 + int(q)) for q in rng.randint(2, 40, len(seq))) if i % 3 == 0 else None
+        reads.append(("sim%d_%s" % (i, tid), seq, qual))
+    return reads

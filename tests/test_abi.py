@@ -51,3 +51,33 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_python_set_order_restatement_matches_the_interpreter():
+    """csrc/pyset.h restates CPython's tuple hash and set probing (the reference's sorted(set(hits), key=start) leaves
+    equal starts in set order, classify_read_with_mams.py:180-253): checked against this interpreter's own sets,
+    including every table size up to the device planner's capacity and repeated insertions."""
+    import ctypes as C
+    import random
+    import numpy as np
+    from ultra_amd import lib
+    L = lib.load()
+    rnd = random.Random(11)
+    sizes = [1, 2, 4, 5, 6, 18, 19, 20, 76, 77, 78, 306, 307, 308, 1228, 1229, 1230, 2048] + [rnd.randint(1, 90) for _ in range(400)]
+    for n in sizes:
+        base = rnd.randint(0, 10 ** rnd.randint(2, 9))
+        seen, lst = set(), []
+        while len(lst) < n:
+            a = base + rnd.randint(0, 4000)
+            t = (rnd.randint(1, 40), a, a + rnd.randint(1, 300))
+            if t not in seen:
+                seen.add(t); lst.append(t)
+        with_repeats = []
+        for t in lst:                       # a key that is already in the set changes nothing when added again
+            with_repeats.append(t)
+            if rnd.random() < 0.3:
+                with_repeats.append(rnd.choice(with_repeats))
+        arr = np.ascontiguousarray(np.array(lst, np.int64).ravel())
+        order = np.zeros(n, np.int32)
+        assert L.ultra_pyset_order(arr.ctypes.data_as(C.POINTER(C.c_int64)), n, order.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        assert [lst[i] for i in order] == list(set(with_repeats)), n

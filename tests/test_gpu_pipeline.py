@@ -2,6 +2,7 @@
 
 ultra_pipe must return, batch by batch and in submission order, exactly what the synchronous path returns, whatever the
 depth; align_single must not care how the reads are grouped into GPU batches."""
+import os
 import queue
 import struct
 import types
@@ -139,3 +140,68 @@ def test_align_single_is_independent_of_gpu_batching(ctx, tmp_path):
     primaries = [f for f in fields if f[4] != "unaligned" and f[10] == "False"]
     assert sum(runs[0][1][1:]) == len(primaries) > len(records) // 4     # one classification count per aligned read
     assert all(f[11] in ("0", "60") for f in primaries)
+
+
+@pytest.mark.parametrize("gpu_batch", [65536, 7])
+def test_align_single_equals_the_reference_on_sirv(ctx, tmp_path, gpu_batch):
+    """tests/golden/align_single_golden.json: the reference's own align_single (modules/align.py:392-560) run on the
+    SIRV annotation, with a transcript of every call it made into find_exons / classify_alignment2 / get_exact_alignment
+    / sam_output.  Here the same reads go through ultra_amd.align.align_single on the GPU; the downstream stages are
+    replayed from the transcript (a call the reference did not make fails the lookup), the base-level alignments come
+    from the GPU batch and must equal the recorded ones, and the SAM rows and classification counts must be the
+    reference's."""
+    import json
+    from tests import helpers
+    from ultra_amd import align, indexer
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "align_single_golden.json")) as f:
+        gold = json.load(f)
+    sirv = os.path.join(here, "golden", "sirv")
+    ann = indexer.build_index(os.path.join(sirv, "SIRV_genes_C_170612a.gtf"), os.path.join(sirv, "SIRV_genes.fasta"), **gold["index"])
+    calls = gold["calls"]
+    used = {k: set() for k in calls}
+
+    def replay(name, key):
+        d = helpers.digest(key)
+        assert d in calls[name], "%s was called with arguments the reference never passed" % name
+        used[name].add(d)
+        return helpers.unjsonable(calls[name][d])
+
+    def find_exons(chr_id, mam_solution, *tables):
+        return replay("find_exons", [chr_id, helpers.mam_key(mam_solution)])
+
+    def classify(chr_id, predicted_splices, *tables):
+        return replay("classify", [chr_id, predicted_splices])
+
+    def exact_batch(jobs):
+        got = align.get_exact_alignment_batch(jobs, ctx=ctx)
+        for job, g in zip(jobs, got):
+            want = replay("exact_alignment", list(job))
+            assert tuple(g) == tuple(want)
+        return got
+
+    def sam_entry(*a, **kw):
+        return replay("sam_entry", [list(a), kw])
+
+    state = align.AlignState(indexer.align_data(ann), ctx=ctx, device=0)
+    try:
+        for run in gold["runs"]:
+            args = types.SimpleNamespace(outfolder=str(tmp_path), index="", gpu_batch_reads=gpu_batch, ultra_state=state,
+                                         downstream=align.Downstream(find_exons, classify, None, sam_entry, exact_alignment_batch=exact_batch),
+                                         **run["args"])
+            qin, qout, qcnt = queue.Queue(), queue.Queue(), queue.Queue()
+            for b in range(0, len(gold["records"]), 20):
+                qin.put([b // 20 + 1, gold["records"][b:b + 20]])
+            qin.put(None)
+            align.align_single(0, qin, qout, qcnt, args)
+            rows = []
+            while not qout.empty():
+                rows.append(qout.get())
+            assert rows == run["rows"], run["name"]
+            counts, want = qcnt.get(), helpers.unjsonable(run["classification_list"])
+            assert counts[1:] == want[1:]
+            assert abs(counts[0] - want[0]) < 1e-9          # a sum of per-read coverages, added in the same order
+    finally:
+        state.close()
+    # every recorded SAM row and alignment was needed by one of the two runs
+    assert used["sam_entry"] == set(calls["sam_entry"]) and used["exact_alignment"] == set(calls["exact_alignment"])

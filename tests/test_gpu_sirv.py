@@ -95,3 +95,52 @@ def test_sirv_reads_land_on_their_genes(ctx, sirv):
         assert score >= 0.5 * len(trimmed[r])
         assert mam_sol and all(m.ref_chr_id == chr_id for m in mam_sol)
         assert value >= 0.5 * len(trimmed[r])
+
+
+def test_simulated_sirv_reads_host_and_device_planner_vs_oracle(ctx, tmp_path):
+    """400 reads simulated from the annotated SIRV transcripts.  A real annotation has what the synthetic worlds lack:
+    segments that start at the same coordinate (alternative 3' ends, the widened segments of short intervals), where
+    the reference's candidate order is the iteration order of a Python set (csrc/pyset.h).  Both planners - host
+    (ultra_plan_create) and device (ultra_mam_stage_nams) - must reproduce the oracle, which runs real Python sets."""
+    from oracle import classify_port
+    from tests import helpers
+    from ultra_amd import align, indexer, seed_wrapper, seeder
+    ann = indexer.build_index(os.path.join(SIRV, "SIRV_genes_C_170612a.gtf"), os.path.join(SIRV, "SIRV_genes.fasta"))
+    refs = indexer.read_fasta(os.path.join(SIRV, "SIRV_genes.fasta"))
+    rng = np.random.RandomState(99)
+    reads = helpers.simulate_transcript_reads(indexer.read_gtf(os.path.join(SIRV, "SIRV_genes_C_170612a.gtf")), refs, rng, 400)
+    path = str(tmp_path / "seeds.txt.gz")
+    seeder.write_seed_file(path, [(a, s) for a, s, _ in reads], ann["ref_part_sequences"], min_len=15)
+    seeds = [(hits, hits_rc) for _, hits, _, hits_rc in seed_wrapper.read_seeds(path)]
+    trimmed = [align.remove_read_polyA_ends(seq, None, 20, 1)[0] for _, seq, _ in reads]
+    locs = align.chain_reads_batch(seeds, ann["max_intron_chr"], 1200000, 0.95, 5, ctx=ctx)
+    instances = []
+    for r, per_read in enumerate(locs):
+        for chr_id, sol, score, is_rc in per_read:
+            instances.append((sol, align.reverse_complement(trimmed[r]) if is_rc else trimmed[r]))
+    assert len(instances) > 300
+    state = align.AlignState(indexer.align_data(ann), ctx=ctx, device=0)
+    try:
+        assert state.dindex is not None
+        five = state.five()
+        want = [classify_port.classify(sol, *five, read, None, 0.6) for sol, read in instances]
+        ties = 0
+        for sol, _ in instances:       # the case this test is for does occur
+            hit = set()
+            for nam in sol:
+                key = align._array('L', [int(v) for v in nam.exon_part_id.split('^')]).tobytes()
+                flat = ann["parts_to_segments"].get(key)
+                if flat is not None:
+                    hit.update((flat[i + 1], flat[i + 2]) for i in range(0, len(flat), 3) if not (flat[i + 2] < nam.x or nam.y < flat[i + 1]))
+            starts = [s for s, _ in hit]
+            ties += len(starts) != len(set(starts))
+        assert ties > 20
+        from ultra_amd import classify_read_with_mams as stage
+        host = stage.main_batch(instances, *five, min_acc=0.6, ctx=ctx, index=state.native)
+        dev = state.mam_stage(instances, 0.6)
+        for name, got in (("host planner", host), ("device planner", dev)):
+            bad = [i for i, (g, w) in enumerate(zip(got, want))
+                   if list(g[0]) != list(w[0]) or g[1] != w[1] or helpers.mam_key(g[2]) != helpers.mam_key(w[2])]
+            assert not bad, (name, len(bad), bad[:5])
+    finally:
+        state.close()

@@ -79,10 +79,13 @@ def annotate_guaranteed_optimal_bound(mems, is_rc, max_intron_chr, max_global_in
     return upper_bound
 
 
-def chain_reads_batch(seed_records, max_intron_chr, max_global_intron, dropoff, max_loc, ctx=None):
+def chain_reads_batch(seed_records, max_intron_chr, max_global_intron, dropoff, max_loc, ctx=None, last_limits=None):
     """seed_records: [(hits, hits_rc)] per read (raw hit lines, seed_wrapper.read_seeds).  Returns per read the
     locations the reference would hand to the MAM stage, in its order: [(chr_id, mem_solution, score, is_rc)]
-    (align.py:429-475, before the duplicate-MAM-solution filter of :493 which needs the MAM results)."""
+    (align.py:429-475, before the duplicate-MAM-solution filter of :493 which needs the MAM results).
+    last_limits, if a list, receives per read the intron limit of the LAST instance the reference's chaining loop
+    worked on (its variable max_allowed_intron as the loop leaves it, :446) - the value its later intron filter
+    (:505) compares every location of the read with, whatever chromosome the location is on."""
     per_read, flat, introns = [], [], []
     for hits, hits_rc in seed_records:
         ub = annotate_guaranteed_optimal_bound(get_mems_from_input(hits), False, max_intron_chr, max_global_intron)
@@ -95,10 +98,11 @@ def chain_reads_batch(seed_records, max_intron_chr, max_global_intron, dropoff, 
     chained = colinear_solver.read_coverage_batch(flat, introns, solver=0, ctx=ctx) if flat else []
     out = []
     for order, base in per_read:
-        all_chainings, best = [], 0
+        all_chainings, best, limit = [], 0, None
         for k, ((chr_id, _), (bound, is_rc, _)) in enumerate(order):
             if bound < best * dropoff:
                 break
+            limit = introns[base + k]
             solutions, value = chained[base + k]
             best = max(best, value)
             for sol in solutions:
@@ -110,6 +114,8 @@ def chain_reads_batch(seed_records, max_intron_chr, max_global_intron, dropoff, 
                 break
             kept.append(loc)
         out.append(kept)
+        if last_limits is not None:
+            last_limits.append(limit)
     return out
 
 
@@ -378,8 +384,9 @@ def align_reads_batch(records, state, args, downstream):
     counts = [0] * 8
     mods = [remove_read_polyA_ends(seq, qual, args.reduce_read_ployA, 1) for _, seq, qual, _, _ in records]
     # ---- phases 1-3: seeds -> instances -> NAM chaining -> location selection ----
+    intron_limit = []
     locations = chain_reads_batch([(hits, hits_rc) for _, _, _, hits, hits_rc in records], state.max_intron_chr,
-                                  args.max_intron, args.dropoff, args.max_loc, ctx=state.ctx)
+                                  args.max_intron, args.dropoff, args.max_loc, ctx=state.ctx, last_limits=intron_limit)
     # ---- phase 4: one MAM stage over every (read, location) ----
     instances, owner = [], []
     rc_cache = {}
@@ -424,7 +431,7 @@ def align_reads_batch(records, state, args, downstream):
                                                                 state.transcripts_to_splices, state.all_splice_pairs_annotations,
                                                                 state.all_splice_sites_annotations)
             largest_intron = max([b.x - a.y for a, b in zip(mam_solution[:-1], mam_solution[1:])]) if len(mam_solution) > 1 else 0
-            if largest_intron > min(state.max_intron_chr[chr_id] + 20000, args.max_intron) and classification != 'FSM':
+            if largest_intron > intron_limit[r] and classification != 'FSM':      # the limit as the chaining loop left it (:446, :505)
                 continue
             jobs.append((read_seq, created_ref_seq, exons_len))
             cand.append((len(jobs) - 1, read_seq, chr_id, classification, predicted_exons, transcript_id, is_rc, covered,

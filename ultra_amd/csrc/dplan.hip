@@ -20,7 +20,7 @@
 //   raw hits (segment, NAM) in NAM order -> sort by (segment, arrival) -> unique hit segments with the first NAM's
 //   start and the last NAM's end; genes of the hit segments -> sort/unique; entry list = small segments of every gene
 //   in gene order, then the hit segments, de-duplicated by first arrival, sorted by (start, arrival) = the reference's
-//   candidate order; flanks in first-seen order.  Two passes (count, scan, fill) give deterministic CSR outputs.
+//   candidate order; hit segments with equal starts in the iteration order of the reference's Python set (pyset.h); flanks in first-seen order.  Two passes (count, scan, fill) give deterministic CSR outputs.
 #include "common.h"
 
 #include <algorithm>
@@ -28,6 +28,7 @@
 #include <string>
 
 #include "plan.h"
+#include "pyset.h"
 
 namespace {
 
@@ -227,13 +228,51 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
             const int run = U + __popcll(m & lt_mask) + (first ? 1 : 0) - 1; // index of this entry's run
             if (i < nh) {
                 const int raw = (int)(uint32_t)kx;
-                if (first) { uh_seg[run] = (int32_t)(kx >> 32); uh_x[run] = A1[raw]; }
+                if (first) { uh_seg[run] = (int32_t)(kx >> 32); uh_x[run] = A1[raw]; uh_full[run] = raw; }
                 if (last) uh_y[run] = A2[raw];
             }
             U += __popcll(m);
         }
     }
     __syncthreads();
+
+    // ---- hit segments that START at the same coordinate: the reference's sorted(set(...), key=start) leaves them in
+    //      the set's iteration order, which decides between identical partial pieces later on (pyset.h) ----
+    if (!too_big && U > 1) {
+        static_assert(pyset::final_size(CAP) * sizeof(uint16_t) <= CAP * sizeof(uint64_t), "the set's table is laid over keysB");
+        bool tie = false;
+        for (int i = lane; i + 1 < U; i += 64) tie |= a.seg[uh_seg[i]].s0 == a.seg[uh_seg[i + 1]].s0;
+        if (__ballot(tie)) {
+            // insertion order = order of first arrival among the raw hits
+            for (int i = lane; i < U; i += 64) keysB[i] = ((uint64_t)(uint32_t)uh_full[i] << 32) | (uint32_t)i;
+            __syncthreads();
+            wave_sort(keysB, U, lane);
+            for (int k = lane; k < U; k += 64) {
+                const int r = (int)(uint32_t)keysB[k];
+                const SegRec sr = a.seg[uh_seg[r]];
+                A1[k] = r;
+                keysA[k] = pyset::tuple3_hash((uint64_t)sr.chr, (uint64_t)sr.s0, (uint64_t)sr.s1);
+            }
+            __syncthreads();
+            uint16_t *table = (uint16_t *)keysB, *list = (uint16_t *)A2;
+            if (lane == 0) genes[0] = (int32_t)pyset::build(keysA, U, table, list);
+            __syncthreads();
+            const int size = genes[0];
+            for (int sl = lane; sl < size; sl += 64) {
+                const int v = table[sl];
+                if (v) uh_full[A1[v - 1]] = sl;
+            }
+            __syncthreads();
+            for (int i = lane; i < U; i += 64)
+                keysA[i] = ((uint64_t)(uint32_t)a.seg[uh_seg[i]].s0 << 32) | ((uint64_t)(uint32_t)uh_full[i] << 12) | (uint32_t)i;
+            __syncthreads();
+            wave_sort(keysA, U, lane);
+            for (int q = lane; q < U; q += 64) { const int r = (int)(keysA[q] & 0xfff); A1[q] = uh_seg[r]; A2[q] = uh_x[r]; uh_full[q] = uh_y[r]; }
+            __syncthreads();
+            for (int q = lane; q < U; q += 64) { uh_seg[q] = A1[q]; uh_x[q] = A2[q]; uh_y[q] = uh_full[q]; }
+            __syncthreads();
+        }
+    }
 
     // ---- get_unique_segment_and_flank_choordinates (:256-300): small segments of every hit gene, then the hit segments ----
     int C0 = 0;

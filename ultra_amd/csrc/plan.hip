@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "plan.h"
+#include "pyset.h"
 
 struct ultra_plan {
     std::vector<uint8_t> arena;
@@ -55,13 +56,32 @@ struct Loc {
     int64_t chr, s0, s1;
     bool operator==(const Loc &o) const { return chr == o.chr && s0 == o.s0 && s1 == o.s1; }
 };
-// order of the reference's sorted(..., key=start); equal starts do not occur among canonical segments of one
-// chromosome - if they did the reference's order would be the iteration order of a Python set (unpinned)
-inline bool loc_less(const Loc &x, const Loc &y)
+// The reference's sorted(set(hits), key=start) on the distinct hits in arrival order: by start, equal starts in the
+// iteration order of the Python set (pyset.h).
+void sort_hits_like_the_reference(std::vector<Loc> &hits)
 {
-    if (x.s0 != y.s0) return x.s0 < y.s0;
-    if (x.s1 != y.s1) return x.s1 < y.s1;
-    return x.chr < y.chr;
+    const size_t n = hits.size();
+    std::vector<std::pair<std::pair<int64_t, uint32_t>, uint32_t>> keyed(n); // ((start, slot), arrival index)
+    bool tie = false;
+    {
+        std::vector<int64_t> starts(n);
+        for (size_t i = 0; i < n; i++) starts[i] = hits[i].s0;
+        std::sort(starts.begin(), starts.end());
+        tie = std::adjacent_find(starts.begin(), starts.end()) != starts.end();
+    }
+    std::vector<uint32_t> slot(n, 0);
+    if (tie) {
+        std::vector<uint64_t> hash(n);
+        for (size_t i = 0; i < n; i++) hash[i] = pyset::tuple3_hash((uint64_t)hits[i].chr, (uint64_t)hits[i].s0, (uint64_t)hits[i].s1);
+        std::vector<uint32_t> table(pyset::final_size((int)n)), list(n);
+        const uint32_t size = pyset::build(hash.data(), (int)n, table.data(), list.data());
+        for (uint32_t s = 0; s < size; s++) if (table[s]) slot[table[s] - 1] = s;
+    }
+    for (size_t i = 0; i < n; i++) keyed[i] = {{hits[i].s0, slot[i]}, (uint32_t)i};
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<Loc> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = hits[keyed[i].second];
+    hits.swap(out);
 }
 
 struct Cand {
@@ -105,6 +125,21 @@ struct PairTable {
 } // namespace
 
 extern "C" const char *ultra_plan_last_error(void) { return g_plan_err.c_str(); }
+
+extern "C" int ultra_pyset_order(const int64_t *triples, int32_t n, int32_t *order)
+{
+    if (n < 0 || (n > 0 && (!triples || !order))) return ULTRA_E_ARG;
+    std::vector<uint64_t> hash((size_t)n);
+    for (int32_t i = 0; i < n; i++) {
+        for (int t = 0; t < 3; t++) if (triples[3 * i + t] < 0 || triples[3 * i + t] >= ((int64_t)1 << 61) - 1) return ULTRA_E_ARG;
+        hash[(size_t)i] = pyset::tuple3_hash((uint64_t)triples[3 * i], (uint64_t)triples[3 * i + 1], (uint64_t)triples[3 * i + 2]);
+    }
+    std::vector<uint32_t> table(pyset::final_size(n)), list((size_t)n);
+    const uint32_t size = pyset::build(hash.data(), n, table.data(), list.data());
+    int32_t m = 0;
+    for (uint32_t s = 0; s < size; s++) if (table[s]) order[m++] = (int32_t)table[s] - 1;
+    return ULTRA_OK;
+}
 
 extern "C" int ultra_index_create(const ultra_index_input *in, ultra_index **out)
 {
@@ -184,9 +219,9 @@ extern "C" int ultra_plan_create(const ultra_index *ix, const ultra_plan_request
                     if (!overlaps(s0, s1, x, y)) continue;
                     const Loc loc{chr, s0, s1};
                     seg_id[k3(loc)] = t_chr;
-                    seg_hits.push_back(loc);
                     auto sp = seg_span.find(k3(loc));
-                    if (sp == seg_span.end()) seg_span[k3(loc)] = {x, y}; else sp->second.second = y;
+                    if (sp == seg_span.end()) { seg_span[k3(loc)] = {x, y}; seg_hits.push_back(loc); } // distinct, in arrival order
+                    else sp->second.second = y;
                 }
             } else {
                 const Loc loc{chr, p0, p1};
@@ -195,8 +230,7 @@ extern "C" int ultra_plan_create(const ultra_index *ix, const ultra_plan_request
                 if (sp == flank_span.end()) flank_span[k3(loc)] = {x, y}; else sp->second.second = y;
             }
         }
-        std::sort(seg_hits.begin(), seg_hits.end(), loc_less);
-        seg_hits.erase(std::unique(seg_hits.begin(), seg_hits.end()), seg_hits.end());
+        sort_hits_like_the_reference(seg_hits);
         // ---- get_unique_segment_and_flank_choordinates (:256-300) ----
         if (!seg_hits.empty()) {
             for (const Loc &loc : seg_hits) {

@@ -72,6 +72,14 @@ def _key(chr_id, a, b):
     return array("L", [chr_id, a, b]).tobytes()
 
 
+def _new_array():       # module-level default factories: the tables keep their default behaviour through pickle
+    return array("L")
+
+
+def _dd_set():
+    return defaultdict(set)
+
+
 class _Part(object):
     __slots__ = ("chr_id", "number", "start", "stop", "positions", "genes", "starts_at", "ends_at")
 
@@ -86,8 +94,8 @@ def _segments_of_parts(parts, exon_span, small_threshold, min_size):
     gene_to_small_segments.  Kept on purpose: a part's segments all share ONE gene set object; the forward widening
     adds its segment every time it is reached (its membership test compares a tuple with byte keys, :168); an exon
     taken over as a segment is booked as a small segment of whichever gene a small-segment loop visited last (:251)."""
-    parts_to_segments = defaultdict(lambda: array("L"))
-    gene_to_small = defaultdict(lambda: array("L"))
+    parts_to_segments = defaultdict(_new_array)
+    gene_to_small = defaultdict(_new_array)
     segment_to_gene, coords = {}, {}
     last_gene = [None]      # the reference's loop variable `gene_id`, which outlives its loops
 
@@ -218,8 +226,8 @@ def build_annotation(exons, flank_size=1000, small_exon_threshold=200, min_segm=
     by_transcript = defaultdict(list)
     for e in exons:
         by_transcript[(e.seqid, e.transcript_id)].append((e.start - 1, e.stop))
-    splices_to_transcripts = defaultdict(lambda: defaultdict(set))
-    pair_annotations = defaultdict(lambda: defaultdict(set))
+    splices_to_transcripts = defaultdict(_dd_set)
+    pair_annotations = defaultdict(_dd_set)
     site_annotations = defaultdict(set)
     max_intron_chr = defaultdict(int)
     for (seqid, tid), spans in by_transcript.items():
@@ -277,19 +285,12 @@ def add_sequences(ann, refs):
     return ann
 
 
-def _plain(obj):
-    """defaultdicts with lambda factories do not pickle: plain containers of the same content."""
-    if isinstance(obj, dict):
-        return {k: _plain(v) for k, v in obj.items()}
-    return obj
-
-
 def write_index(folder, ann):
     """The index folder `uLTRA align` reads (uLTRA:86-99, :168-172): one pickle per dictionary, same file names."""
     os.makedirs(folder, exist_ok=True)
     for name, value in ann.items():
         with open(os.path.join(folder, name + ".pickle"), "wb") as fh:
-            pickle.dump(_plain(value), fh, pickle.HIGHEST_PROTOCOL)
+            pickle.dump(value, fh, pickle.HIGHEST_PROTOCOL)
 
 
 def build_index(gtf, fasta, folder=None, flank_size=1000, small_exon_threshold=200, min_segm=25):
@@ -304,4 +305,4 @@ def build_index(gtf, fasta, folder=None, flank_size=1000, small_exon_threshold=2
 def align_data(ann):
     """The 13 dictionaries of ultra_amd.align.import_data, in its order."""
     from .align import INDEX_FILES
-    return tuple(_plain(ann[name]) for name in INDEX_FILES)
+    return tuple(ann[name] for name in INDEX_FILES)

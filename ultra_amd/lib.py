@@ -24,7 +24,7 @@ EXPORTS = [
     "ultra_chain_mams_batch_noalloc", "ultra_chain_noalloc_capacity",
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
     "ultra_index_create", "ultra_index_destroy", "ultra_plan_create", "ultra_plan_input", "ultra_plan_cands",
-    "ultra_plan_destroy", "ultra_plan_last_error",
+    "ultra_plan_destroy", "ultra_plan_last_error", "ultra_pyset_order",
     "ultra_dindex_create", "ultra_dindex_destroy", "ultra_dindex_last_error", "ultra_mam_stage_nams", "ultra_mam_counts",
     "ultra_mam_fetch_plan",
     "ultra_pipe_create", "ultra_pipe_destroy", "ultra_pipe_last_error", "ultra_pipe_submit", "ultra_pipe_pending",
@@ -135,6 +135,7 @@ def load():
     lib.ultra_plan_destroy.restype = None
     lib.ultra_plan_last_error.argtypes = []
     lib.ultra_plan_last_error.restype = C.c_char_p
+    lib.ultra_pyset_order.argtypes = [i64p, C.c_int32, i32p]
     lib.ultra_dindex_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.ultra_dindex_destroy.argtypes = [vp]
     lib.ultra_dindex_destroy.restype = None
