@@ -377,3 +377,116 @@ def test_soft_masked_and_iupac_batches(ctx):
     finally:
         dix.close(); ix.close()
     assert all(_same(a, b) for a, b in zip(want, dev))
+
+
+def _hand_world():
+    """A hand-built chromosome for the long call shapes (classify_read_with_mams.py:311-312, :374-377):
+    flank [48000, 50000) | part [50000, 50900) of three exons | flank [50900, 52900) ... part [100000, 125000): one
+    25 kb segment (a long last exon)."""
+    from array import array
+    from collections import defaultdict
+    from tests import helpers
+    rng = np.random.RandomState(17)
+    key = lambda a, b: array("L", [1, a, b]).tobytes()
+    genome = {}
+
+    def seq(a, b):
+        genome[(a, b)] = helpers.rand_seq(rng, b - a)
+        return genome[(a, b)]
+    segs = {key(50000, 50300): seq(50000, 50300), key(50300, 50600): seq(50300, 50600), key(50600, 50900): seq(50600, 50900),
+            key(100000, 125000): seq(100000, 125000)}
+    flanks = {key(48000, 50000): seq(48000, 50000), key(50900, 52900): seq(50900, 52900), key(98000, 100000): seq(98000, 100000)}
+    parts = {key(50000, 50900): array("L", [1, 50000, 50300, 1, 50300, 50600, 1, 50600, 50900]), key(100000, 125000): array("L", [1, 100000, 125000])}
+    seg_gene = {key(50000, 50300): {"g1"}, key(50300, 50600): {"g1"}, key(50600, 50900): {"g1"}, key(100000, 125000): {"g2"}}
+    small = defaultdict(lambda: array("L"))
+    return genome, (segs, flanks, parts, seg_gene, small)
+
+
+def _nams(pieces, part_of):
+    """pieces: [(ref start, read start, length)] exact seeds -> Mem list in reference order."""
+    from ultra_amd.synth import Mem
+    out = []
+    for j, (x, c, n) in enumerate(sorted(pieces)):
+        out.append(Mem(x, x + n - 1, c, c + n - 1, n, j, part_of(x)))
+    return out
+
+
+def test_long_call_shapes_at_stage_level(ctx):
+    """Call shape (iii) - the read lies inside a segment at least 0.8 x its length (:374-377) - with 5-15 kb reads in a
+    25 kb segment, and a 2 kb flank under a 2.2-2.6 kb read (shapes (i) and (iii) on the same candidate, partial flank
+    pieces, :311-312), through the whole stage with the host and the device planner, against the oracle."""
+    from oracle import classify_port
+    from tests import helpers
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import index as native
+    genome, idx = _hand_world()
+    rng = np.random.RandomState(23)
+
+    def part_of(x):
+        for a, b in ((48000, 50000), (50000, 50900), (50900, 52900), (98000, 100000), (100000, 125000)):
+            if a <= x < b:
+                return "1^%d^%d" % (a, b)
+        raise AssertionError(x)
+
+    def seeds_along(ref_start, read, truth_start, n_seeds, ln=18):
+        """exact seeds can only be planted where the read still equals the genome: look for them"""
+        flat = "".join(genome[k] for k in sorted(genome) if k[0] >= truth_start[0] and k[0] < truth_start[1])
+        base = truth_start[0]
+        out = []
+        for _ in range(400):
+            c = int(rng.randint(0, len(read) - ln))
+            at = flat.find(read[c:c + ln])
+            if at >= 0 and flat.find(read[c:c + ln], at + 1) < 0:
+                x = base + at
+                if part_of(x) == part_of(x + ln - 1):
+                    out.append((x, c, ln))
+            if len(out) >= n_seeds:
+                break
+        # colinear subset
+        out.sort()
+        keep, last_c = [], -1
+        for x, c, n in out:
+            if c > last_c:
+                keep.append((x, c, n)); last_c = c + n
+        return keep
+
+    pairs = []
+    long_seg = genome[(100000, 125000)]
+    for ln in (5000, 7000, 9000, 12000, 15000, 15000, 6000, 11000):
+        a = int(rng.randint(0, len(long_seg) - ln))
+        read = helpers.mutate(rng, long_seg[a:a + ln], float(rng.choice([0.03, 0.08, 0.12])))
+        nams = seeds_along(100000 + a, read, (100000, 125000), 12)
+        assert len(nams) >= 2
+        pairs.append((_nams(nams, part_of), read))
+    # a read running from the 3' flank of the upstream gene into the long exon start: flank + contained shapes together
+    span = genome[(98000, 100000)][-1500:] + long_seg[:6000]
+    read = helpers.mutate(rng, span, 0.06)
+    pairs.append((_nams(seeds_along(98500, read, (98000, 125000), 14), part_of), read))
+    # 2 kb flank x 2.2-2.6 kb reads: the flank in front of the three-exon part, and the one behind it
+    for lo, hi in ((48000, 50400), (47990 + 10, 50250), (50500, 52900), (50700, 52900)):
+        lo = max(lo, 48000)
+        ref = "".join(genome[k] for k in sorted(genome) if 48000 <= k[0] < 52900)
+        piece = ref[lo - 48000:hi - 48000]
+        for rate in (0.0, 0.05, 0.1):
+            read = helpers.mutate(rng, piece, rate)
+            nams = seeds_along(lo, read, (48000, 52900), 10)
+            assert len(nams) >= 2
+            pairs.append((_nams(nams, part_of), read))
+    assert sum(len(r) >= 4500 for _, r in pairs) >= 9
+    want = [classify_port.classify(sol, *idx, read, None, 0.6) for sol, read in pairs]
+    assert sum(1 for w in want if w[2]) >= len(pairs) - 2
+    labels = "".join(m.mam_id for w in want for m in w[2])
+    assert "_full_flank" in labels or "_partial_flank" in labels
+    assert any(m.c == 0 and m.d == len(read) - 1 for w, (_, read) in zip(want, pairs) for m in w[2] if len(read) >= 4500)   # shape (iii) taken
+    got = stage.main_batch(pairs, *idx, min_acc=0.6, ctx=ctx)
+    assert all(_same(a, b) for a, b in zip(want, got))
+    ix = native.NativeIndex(*idx)
+    dix = native.DeviceIndex(ix)
+    try:
+        flat = native.flatten_instances(pairs)
+        ctx.mam_stage_nams(dix, *flat)
+        stage.run_staged(ctx, 0.6)
+        dev = stage.results_from_names(ctx.mam_fetch(want_names=True), np.diff(flat[5]).tolist())
+    finally:
+        dix.close(); ix.close()
+    assert all(_same(a, b) for a, b in zip(want, dev))
