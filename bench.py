@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (default 8)")
     ap.add_argument("--lanes", type=int, default=0, help="launch lanes (HIP streams) per context, 0 = one per hardware queue")
     ap.add_argument("--slots", type=int, default=0, help="end positions kept per pair in the first pass, 0 = library default")
+    ap.add_argument("--banded-starts", type=int, default=-1, help="start pass: 1 banded, 0 full height, -1 library default")
     ap.add_argument("--check", type=int, default=48, help="instances verified against the oracle (rank 0)")
     return ap.parse_args()
 
@@ -200,6 +201,8 @@ def main():
         cfg["launch_lanes"] = args.lanes
     if args.slots:
         cfg["loc_slots"] = args.slots
+    if args.banded_starts >= 0:
+        cfg["banded_starts"] = args.banded_starts
     t0 = time.perf_counter()
     dix = native_index.DeviceIndex(nix, local)
     dindex_s = time.perf_counter() - t0

@@ -46,6 +46,9 @@ typedef struct ultra_cfg {
     int32_t nam_switch_n;     /* >= this many NAMs -> n log n NAM solver (align.py:448)                      = 90 */
     int32_t launch_lanes;     /* HIP streams the independent launches of one pass are dealt over, 1..8; 0 = one per
                                  hardware queue of the process (GPU_MAX_HW_QUEUES in the environment, else 4) = 0 */
+    int32_t banded_starts;    /* 1 = start positions of locations with distance <= 59 by a banded reverse pass, lane per
+                                 location (same results, 24 % fewer instructions, but 0.6 ms slower per 262144-read
+                                 batch than the lane-group pass it replaces: kept as an option); 0 = full height   = 0 */
 } ultra_cfg;
 
 void ultra_cfg_default(ultra_cfg *cfg);

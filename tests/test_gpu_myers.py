@@ -162,3 +162,34 @@ def test_banded_traceback_skewed_paths(ctx, mix):
         assert (got["ed"] > 54).any()
         if block == 0:
             assert ((got["ed"] >= 0) & (got["ed"] <= 22)).any() and ((got["ed"] > 22) & (got["ed"] <= 54)).any()
+
+
+def test_banded_and_full_height_start_pass_agree(ctx):
+    """Start positions from the full-height reverse pass (default) and from the banded one (cfg banded_starts=1: lane
+    per location for distances <= 59, dense full-height lists beyond) are the same and equal the oracle: many
+    locations per pair (low-complexity sequences), locations whose window runs into the target's first column,
+    distances on either side of every band-class limit (5, 11, 27, 59), queries in every size class."""
+    from ultra_amd import lib
+    rng = np.random.RandomState(21)
+    full = lib.Context(0, cfg={"banded_starts": 1})
+    try:
+        cases = [((5, 64), (20, 300), 2500, (0.0, 0.1, 0.25, 0.38), "ACGT"),
+                 ((5, 40), (40, 400), 1500, (0.0, 0.2), "AC"),                       # dozens of tied end columns
+                 ((40, 300), (60, 500), 2000, (0.02, 0.08, 0.2, 0.35), "ACGT"),
+                 ((200, 700), (150, 900), 700, (0.05, 0.1, 0.2, 0.3), "ACGT"),       # targets shorter than queries too
+                 ((600, 1500), (900, 2400), 120, (0.03, 0.08, 0.13, 0.3), "ACGT"),
+                 ((1500, 2600), (2000, 3500), 40, (0.02, 0.06, 0.12), "ACGTN")]
+        seen = set()
+        for qr, tr, n, rates, alpha in cases:
+            pairs = helpers.make_pairs(rng, n, qr, tr, kmode="ref", planted=0.9, rates=rates, alpha=alpha)
+            a = _check(ctx, pairs)
+            b = _check(full, pairs)
+            assert np.array_equal(a["loc_start"], b["loc_start"]) and np.array_equal(a["loc_end"], b["loc_end"])
+            ed = a["ed"][a["ed"] >= 0]
+            for lim in (5, 11, 27, 59, 123, 187):
+                if (ed <= lim).any() and (ed > lim).any():
+                    seen.add(lim)
+        assert seen == {5, 11, 27, 59, 123, 187}
+        assert (a["n_loc"] >= 1).any()
+    finally:
+        full.close()

@@ -16,6 +16,7 @@ void ultra_cfg_default(ultra_cfg *cfg)
     cfg->banded_traceback = 1;
     cfg->nam_switch_n = 90;    // align.py:448
     cfg->launch_lanes = 0;
+    cfg->banded_starts = 0;    // measured slower than the full-height pass on the bench workload (dead ends)
 }
 
 int ultra_device_count(void)

@@ -70,7 +70,7 @@ struct MyersState {
     float ms[5] = {0, 0, 0, 0, 0};
     int64_t total_loc = 0, total_hit = 0;
     DevBuf seq, rseq, qoff, qlen, toff, tlen, k, ed, nloc, slots, packed, scanned, blocksum, locoff, hitoff,
-        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2;
+        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2, startitems, startinfo;
     // staging: raw bytes, byte -> code table (+ presence mask), the pairs as the caller ordered them, sort scratch,
     // sorted position -> caller's index and its inverse, per-class statistics, unsorted work items
     DevBuf raw, lut, u_qoff, u_qlen, u_toff, u_tlen, u_k, skeys, perm_d, inv_d, stats, worktmp;

@@ -49,17 +49,20 @@ struct MyArgs {
     int32_t Lmax;
     uint8_t *ops; const int64_t *ops_off; int32_t *n_ops;
     int64_t begin, end;
-    int32_t *wflag; // per work item of a forward launch: some pair has more end columns than first-pass slots
+    int32_t *wflag;  // forward launch: dense list of the work items in which some pair has more end columns than first-pass slots
+    int32_t *wcount; // its length (one counter per register bucket)
     // start pass: the work items of a launch follow from the location range of each size class, so they are
     // computed from blockIdx (heaviest class first) instead of being listed by the host
     struct { int32_t cls, first_block; int64_t b, e; } rr[4];
     int32_t n_rr;
     int32_t nbb;    // lane-group traceback: 64-row blocks stored per column (the ones the path's band crosses); 0 = all
+    const int32_t *rev_items; // start pass over a list of locations (what the banded start kernels left), or nullptr = the range itself
 };
 
 struct Item {
     const uint8_t *q, *t;
     int32_t m, n, k, pair, best;
+    int32_t loc; // start pass: the location this item stands for
     bool valid;
 };
 
@@ -67,7 +70,7 @@ template <int MODE> __device__ __forceinline__ Item setup_item(const MyArgs &a, 
 {
     Item it;
     it.valid = item < a.end;
-    it.q = a.seq; it.t = a.seq; it.m = 1; it.n = 0; it.k = 0; it.pair = 0; it.best = 0;
+    it.q = a.seq; it.t = a.seq; it.m = 1; it.n = 0; it.k = 0; it.pair = 0; it.best = 0; it.loc = 0;
     if (!it.valid) return it;
     if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
         int32_t p = (int32_t)item;
@@ -78,8 +81,10 @@ template <int MODE> __device__ __forceinline__ Item setup_item(const MyArgs &a, 
         it.k = (k < 0 || k > it.m) ? it.m : k;
         if (MODE == MODE_FWD_EXACT) it.valid = a.nloc[p] > a.slot_cap;
     } else if (MODE == MODE_REV) {
-        int32_t p = a.loc_pair[item];
-        int32_t e = a.loc_end[item];
+        const int32_t loc = a.rev_items ? a.rev_items[item] : (int32_t)item;
+        int32_t p = a.loc_pair[loc];
+        int32_t e = a.loc_end[loc];
+        it.loc = loc;
         it.pair = p;
         it.m = a.q_len[p];
         it.best = a.ed[p];
@@ -441,9 +446,9 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
         if (MODE == MODE_FWD) {
             if (it.valid) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
             const bool over = __any(it.valid && cnt > out_cap);
-            if (a.wflag && lane == 0) a.wflag[blockIdx.x] = over;
+            if (a.wflag && over && lane == 0) a.wflag[atomicAdd(a.wcount, 1)] = (int32_t)blockIdx.x;
         } else if (MODE == MODE_REV) {
-            if (it.valid) a.loc_start[base + lane] = a.loc_end[base + lane] - last;
+            if (it.valid) a.loc_start[it.loc] = a.loc_end[it.loc] - last;
         } else if (MODE == MODE_NW) {
             __threadfence();
             if (it.valid) {
@@ -613,9 +618,9 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         if (MODE == MODE_FWD) {
             if (it.valid && g == G - 1) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
             const bool over = __any(it.valid && g == G - 1 && cnt > out_cap);
-            if (a.wflag && lane == 0) a.wflag[blockIdx.x] = over;
+            if (a.wflag && over && lane == 0) a.wflag[atomicAdd(a.wcount, 1)] = (int32_t)blockIdx.x;
         } else if (MODE == MODE_REV) {
-            if (it.valid && g == G - 1) a.loc_start[base + p] = a.loc_end[base + p] - last;
+            if (it.valid && g == G - 1) a.loc_start[it.loc] = a.loc_end[it.loc] - last;
         } else if (MODE == MODE_NW) {
             __threadfence();
             {
@@ -657,9 +662,9 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
 {
     extern __shared__ uint64_t lds[];
     if ((int32_t)blockIdx.x >= n) return;
-    if (MODE == MODE_FWD_EXACT && !a.wflag[blockIdx.x]) return; // the forward launch over the same list left the flag
     WorkItem wi;
-    if (list) wi = list[blockIdx.x];
+    if (MODE == MODE_FWD_EXACT) wi = list[a.wflag[blockIdx.x]]; // the forward launch over the same list left these
+    else if (list) wi = list[blockIdx.x];
     else {
         int r = 0;
         while (r + 1 < a.n_rr && (int32_t)blockIdx.x >= a.rr[r + 1].first_block) r++;
@@ -1031,6 +1036,250 @@ __global__ void __launch_bounds__(64) myers_band32(MyArgs a, const int32_t *item
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// banded start pass: lane-per-location, reversed strings, the same sliding window
+// ------------------------------------------------------------------------------------------------
+// edlib finds the start of a location by aligning the reversed query against the reversed target prefix that ends
+// at the location's end column and taking the LAST column whose bottom-row score equals the known distance
+// (edlib.cpp, obtainAlignment -> SHW on the reversed sequences; the full-height version of this is
+// myers_mega<MODE_REV>).  The distance `best` is known here, so only cells within |row - column| <= best matter:
+// 2 best + 1 diagonals.  The window slides exactly as in the traceback kernels; nothing is stored.  The bottom-row
+// score is tracked without ever holding a column of scores: S = D[c][c] follows diagonal 0 (one D0 bit per
+// column); at the first column that can hold an end (c0 = m - 1 - best) the vertical deltas between diagonal 0 and
+// row m - 1 are summed once (population counts), and from then on D[m-1][c] follows the horizontal delta of that row.
+// Values outside the band are over-estimates, never under-estimates: the test D <= best is exact.
+// Needs 2 best <= rows - 10; the locations beyond go through myers_mega<MODE_REV> (rev_items).
+// Only the narrow classes (32, 64, 128 rows: distance <= 59): a lane that carries 4 or 6 words through every
+// column runs longer than the lane groups of the full-height kernels, which split a column over 4 - 64 lanes
+// (measured: 3.0 ms for the 384-row class against 1.9 ms for the whole m = 513..2048 bucket at full height).
+constexpr int kStartBandClasses = 3;
+__device__ __forceinline__ int band_start_class(int best) // 0..2, kBandFallback = none
+{
+    int c = 0;
+    while (c < kStartBandClasses && 2 * best > band_rows(c) - 10) c++;
+    return c < kStartBandClasses ? c : kBandFallback;
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64) myers_bstart32(MyArgs a, const int32_t *items, int64_t n_items)
+{
+    constexpr int TOP = 15;
+    const int lane = threadIdx.x;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n_items; base += (int64_t)gridDim.x * 64) {
+        const bool valid = base + lane < n_items;
+        int loc = 0, m = 1, L = 0, best = 0, e = 0;
+        const uint8_t *q = a.rseq, *t = a.rseq;
+        if (valid) {
+            loc = items[base + lane];
+            const int p = a.loc_pair[loc];
+            e = a.loc_end[loc];
+            m = a.q_len[p]; best = a.ed[p];
+            L = m + best < e + 1 ? m + best : e + 1;
+            q = a.rseq + (a.N - a.q_off[p] - m);
+            t = a.rseq + (a.N - a.t_off[p] - (int64_t)(e + 1));
+        }
+        const int off = (-best - 1 + TOP) & ~7;
+        const int bt = TOP - off;                 // window bit of diagonal 0 (in the alignment of the updated column)
+        uint32_t PL[NP], VP, VN = 0;
+        uint64_t qw = 0, tw = 0, qwn = 0, twn = 0;
+        auto qblock = [&](int r) { return (r >= 0 && r < m) ? load8(q + r) : (uint64_t)0; };
+        auto prefetch = [&](int cn) {
+            twn = (cn >= 0 && cn < L) ? load8(t + cn) : 0;
+            qwn = qblock(TOP + 1 + off + cn);
+        };
+        auto push_row = [&](uint32_t code1) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) PL[k] = __builtin_amdgcn_alignbit(code1 >> k, PL[k], 1);
+        };
+#pragma unroll
+        for (int k = 0; k < NP; k++) PL[k] = 0;
+        {
+            const int r_end = TOP + 1 + off, r0 = off - TOP - 1;
+            int ri = r0 < 0 ? (r_end < 0 ? r_end : 0) : r0;
+            uint64_t cur = 0, nxt = qblock(ri);
+            while (ri < r_end) {
+                if ((ri & 7) == 0) { cur = nxt; nxt = qblock(ri + 8); }
+                push_row((ri >= 0 && ri < m) ? (uint32_t)(cur & 0xff) + 1u : 0u);
+                cur >>= 8;
+                ri++;
+            }
+        }
+        {
+            const int z = TOP + 1 - off; // bit b <-> row -1 - TOP + off + b >= 0
+            VP = z <= 0 ? ~0u : z >= 32 ? 0u : (~0u) << z;
+        }
+        const int c0 = m - 1 - best > 0 ? m - 1 - best : 0;
+        int S = 0, Dm = 0, last = 0;
+        const int Lmax = wave_max_i32(L);
+        prefetch(0);
+        for (int c = 0; c < Lmax; c++) {
+            if ((c & 7) == 0) { tw = twn; qw = qwn; prefetch(c + 8); }
+            const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
+            tw >>= 8;
+            uint32_t Eq = PL[0] ^ (((tc1 >> 0) & 1u) - 1u);
+#pragma unroll
+            for (int kk = 1; kk < NP; kk++) Eq = bop3<0x60>(Eq, PL[kk], ((tc1 >> kk) & 1u) - 1u);
+            const uint32_t sum = (Eq & VP) + VP;
+            const uint32_t D0 = bop3<0xBE>(sum, VP, Eq) | VN;
+            const uint32_t HP = bop3<0xF1>(VN, D0, VP);
+            const uint32_t HN = D0 & VP;
+            const uint32_t X = D0 >> 1;
+            VN = X & HP;
+            VP = bop3<0xF1>(HN, X, HP);
+            // D0 / HP / HN sit one bit higher than the updated column's alignment
+            S += 1 - (int)((D0 >> ((bt + 1) & 31)) & 1u);
+            const int bm = bt + (m - 1 - c);     // window bit of row m - 1 in this column
+            if (c == c0) {
+                const uint32_t mask = (bm >= 31 ? ~0u : ((2u << (bm & 31)) - 1u)) & ~((2u << (bt & 31)) - 1u); // bits bt + 1 .. bm
+                Dm = S + __popc(VP & mask) - __popc(VN & mask);
+            } else if (c > c0) {
+                Dm += (int)((HP >> ((bm + 1) & 31)) & 1u) - (int)((HN >> ((bm + 1) & 31)) & 1u);
+            }
+            if (c >= c0 && c < L && Dm <= best) last = c;
+            const int r = TOP + 1 + off + c;
+            push_row((r >= 0 && r < m) ? (uint32_t)(qw & 0xff) + 1u : 0u);
+            qw >>= 8;
+        }
+        if (valid) a.loc_start[loc] = e - last;
+    }
+}
+
+template <int WB, int NP>
+__global__ void __launch_bounds__(64) myers_bstart(MyArgs a, const int32_t *items, int64_t n_items)
+{
+    constexpr int TOP = 32 * WB - 1;
+    const int lane = threadIdx.x;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n_items; base += (int64_t)gridDim.x * 64) {
+        const bool valid = base + lane < n_items;
+        int loc = 0, m = 1, L = 0, best = 0, e = 0;
+        const uint8_t *q = a.rseq, *t = a.rseq;
+        if (valid) {
+            loc = items[base + lane];
+            const int p = a.loc_pair[loc];
+            e = a.loc_end[loc];
+            m = a.q_len[p]; best = a.ed[p];
+            L = m + best < e + 1 ? m + best : e + 1;
+            q = a.rseq + (a.N - a.q_off[p] - m);
+            t = a.rseq + (a.N - a.t_off[p] - (int64_t)(e + 1));
+        }
+        const int off = (-best - 1 + TOP) & ~7;
+        const int bt = TOP - off;
+        uint64_t PL[NP][WB], VP[WB], VN[WB];
+        uint64_t qw = 0, tw = 0, qwn = 0, twn = 0;
+        auto qblock = [&](int r) { return (r >= 0 && r < m) ? load8(q + r) : (uint64_t)0; };
+        auto prefetch = [&](int cn) {
+            twn = (cn >= 0 && cn < L) ? load8(t + cn) : 0;
+            qwn = qblock(TOP + 1 + off + cn);
+        };
+        auto push_row = [&](uint32_t code1) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+#pragma unroll
+                for (int w = 0; w < WB - 1; w++) PL[k][w] = shr1_in(PL[k][w], (uint32_t)PL[k][w + 1]);
+                PL[k][WB - 1] = shr1_in(PL[k][WB - 1], code1 >> k);
+            }
+        };
+        // bit i of a window vector (i < 64 WB), without indexing registers dynamically
+        auto bit_of = [&](const uint64_t (&v)[WB], int i) {
+            uint64_t wsel = v[0];
+#pragma unroll
+            for (int w = 1; w < WB; w++) wsel = (i >> 6) == w ? v[w] : wsel;
+            return (int)((wsel >> (i & 63)) & 1);
+        };
+#pragma unroll
+        for (int k = 0; k < NP; k++)
+#pragma unroll
+            for (int w = 0; w < WB; w++) PL[k][w] = 0;
+        {
+            const int r_end = TOP + 1 + off, r0 = off - TOP - 1;
+            int ri = r0 < 0 ? (r_end < 0 ? r_end : 0) : r0;
+            uint64_t cur = 0, nxt = qblock(ri);
+            while (ri < r_end) {
+                if ((ri & 7) == 0) { cur = nxt; nxt = qblock(ri + 8); }
+                push_row((ri >= 0 && ri < m) ? (uint32_t)(cur & 0xff) + 1u : 0u);
+                cur >>= 8;
+                ri++;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < WB; w++) {
+            const int z = TOP + 1 - off - 64 * w;
+            VP[w] = z <= 0 ? ~(uint64_t)0 : z >= 64 ? 0 : (~(uint64_t)0) << z;
+            VN[w] = 0;
+        }
+        const int c0 = m - 1 - best > 0 ? m - 1 - best : 0;
+        int S = 0, Dm = 0, last = 0;
+        const int Lmax = wave_max_i32(L);
+        prefetch(0);
+        for (int c = 0; c < Lmax; c++) {
+            if ((c & 7) == 0) { tw = twn; qw = qwn; prefetch(c + 8); }
+            const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
+            tw >>= 8;
+            uint64_t Eq[WB];
+            {
+                uint32_t mk[NP];
+#pragma unroll
+                for (int kk = 0; kk < NP; kk++) mk[kk] = ((tc1 >> kk) & 1u) - 1u;
+#pragma unroll
+                for (int w = 0; w < WB; w++) {
+                    uint32_t el = (uint32_t)PL[0][w] ^ mk[0], eh = (uint32_t)(PL[0][w] >> 32) ^ mk[0];
+#pragma unroll
+                    for (int kk = 1; kk < NP; kk++) {
+                        el = bop3<0x60>(el, (uint32_t)PL[kk][w], mk[kk]);
+                        eh = bop3<0x60>(eh, (uint32_t)(PL[kk][w] >> 32), mk[kk]);
+                    }
+                    Eq[w] = pack64(el, eh);
+                }
+            }
+            uint64_t D0[WB], HP[WB], HN[WB];
+            uint64_t carry = 0;
+#pragma unroll
+            for (int w = 0; w < WB; w++) {
+                const uint64_t x = Eq[w] & VP[w];
+                const uint64_t s1 = x + VP[w];
+                const uint64_t s2 = s1 + carry;
+                carry = (uint64_t)((s1 < x) | (s2 < s1));
+                D0[w] = bop3_64<0xBE>(s2, VP[w], Eq[w]) | VN[w];
+                HP[w] = bop3_64<0xF1>(VN[w], D0[w], VP[w]);
+                HN[w] = D0[w] & VP[w];
+            }
+#pragma unroll
+            for (int w = 0; w < WB; w++) {
+                const uint64_t X = shr1_in(D0[w], w + 1 < WB ? (uint32_t)D0[w + 1] : 0u);
+                VN[w] = X & HP[w];
+                VP[w] = bop3_64<0xF1>(HN[w], X, HP[w]);
+            }
+            S += 1 - bit_of(D0, bt + 1);
+            const int bm = bt + (m - 1 - c);
+            if (c == c0) {
+                int acc = 0;
+#pragma unroll
+                for (int w = 0; w < WB; w++) { // bits bt + 1 .. bm of the window
+                    const int lo = bt + 1 - 64 * w, hi = bm - 64 * w; // inclusive, relative to this word
+                    if (hi < 0 || lo > 63) continue;
+                    const uint64_t above = lo <= 0 ? ~(uint64_t)0 : (~(uint64_t)0) << lo;
+                    const uint64_t below = hi >= 63 ? ~(uint64_t)0 : (((uint64_t)2 << hi) - 1);
+                    const uint64_t mask = above & below;
+                    acc += __popcll(VP[w] & mask) - __popcll(VN[w] & mask);
+                }
+                Dm = S + acc;
+            } else if (c > c0) {
+                Dm += bit_of(HP, bm + 1) - bit_of(HN, bm + 1);
+            }
+            if (c >= c0 && c < L && Dm <= best) last = c;
+            const int r = TOP + 1 + off + c;
+            push_row((r >= 0 && r < m) ? (uint32_t)(qw & 0xff) + 1u : 0u);
+            qw >>= 8;
+        }
+        if (valid) a.loc_start[loc] = e - last;
+    }
+}
+
+// Sort key of every location for the start pass: band class by 2 x distance, then the number of columns, longest
+// first; locations beyond every band class are keyed by the size class of their query (dense lists for
+// myers_mega<MODE_REV>).  Same layout as k_band_keys, so k_band_bounds serves both.
+__global__ void __launch_bounds__(256) k_start_keys(MyArgs a, int64_t n_loc, uint32_t *keys, int32_t *idx);
+
 // Sort key of every hit: band class by its distance (band rows needed: 2*ed + 3), then the length
 // of its first location, longest first - the lanes of a wavefront then run equally long.  Hits beyond
 // every band class are keyed by the size class of their query instead: each full-height kernel then
@@ -1083,6 +1332,19 @@ __global__ void k_band_bounds(const uint32_t *keys, int64_t n, int32_t *info)
         if (lo < n && (keys[lo] >> kBandLBits) == (uint32_t)g) maxl = (int32_t)(((1u << kBandLBits) - 1u) - (keys[lo] & ((1u << kBandLBits) - 1u)));
         info[kBandBounds + g] = maxl;
     }
+}
+
+__global__ void __launch_bounds__(256) k_start_keys(MyArgs a, int64_t n_loc, uint32_t *keys, int32_t *idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_loc) return;
+    const int32_t p = a.loc_pair[i];
+    const int best = a.ed[p], m = a.q_len[p];
+    const uint32_t L = (uint32_t)(m + best); // columns of the reverse pass (an end column close to the target's start has fewer)
+    const uint32_t c = (uint32_t)band_start_class(best);
+    if (c < kBandFallback) keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
+    else keys[i] = (c << kBandLBits) | (size_class_of(m) << kFullLBits) | (((1u << kFullLBits) - 1u) - (L < (1u << kFullLBits) ? L : (1u << kFullLBits) - 1u));
+    idx[i] = (int32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1244,6 +1506,7 @@ template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket,
 {
     if (n <= 0) return hipSuccess;
     a.wflag = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ctx->my.buckets[bucket].fwd_flag.as<int32_t>() : nullptr;
+    a.wcount = (int32_t *)(ctx->my.bounds.as<int64_t>() + 120) + bucket;
     const size_t shmem = (size_t)a.S * bucket_wmax(bucket) * 64 * sizeof(uint64_t);
     hipStream_t cs = ctx->lane(bucket);
     const void *fn = bucket == 0 ? (const void *)myers_mega<MODE, 0> : bucket == 1 ? (const void *)myers_mega<MODE, 1>
@@ -1302,7 +1565,7 @@ void ultra_myers_free(ultra_ctx *ctx)
     DevBuf *bufs[] = {&st.seq, &st.rseq, &st.qoff, &st.qlen, &st.toff, &st.tlen, &st.k, &st.ed, &st.nloc, &st.slots,
                       &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
                       &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff,
-                      &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp, &st.trace2,
+                      &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp, &st.trace2, &st.startitems, &st.startinfo,
                       &st.raw, &st.lut, &st.u_qoff, &st.u_qlen, &st.u_toff, &st.u_tlen, &st.u_k, &st.skeys, &st.perm_d, &st.inv_d, &st.stats, &st.worktmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -1641,6 +1904,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ultra_drain_guard drain(ctx); // any early return below first waits for what has been enqueued
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.firstins.p, 0, (size_t)n * 4, s));
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.nops.p, 0, (size_t)n * 4, s));
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bounds.as<int64_t>() + 120, 0, kBuckets * 4, s)); // lengths of the buckets' re-run lists
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[0], s));
     // ---- pass 1: forward HW ----
     ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
@@ -1672,6 +1936,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, s, st.scanned.as<uint64_t>(), st.packed.as<uint64_t>(),
                        st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), n);
     int64_t h_overflow[kBuckets] = {0, 0, 0, 0, 0};
+    int32_t h_rerun[kBuckets] = {0, 0, 0, 0, 0}; // work items to run again without a limit on the end columns
     {
         // class boundaries (+ totals) to the host: one small copy, the only mid-batch synchronisation
         std::vector<int64_t> pos;
@@ -1686,6 +1951,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ultra_drain_guard drain_b(ctx); // pos / hb are copy endpoints
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb.data(), dout, npz * 16, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_overflow, d_overflow, kBuckets * 8, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_rerun, st.bounds.as<int64_t>() + 120, kBuckets * 4, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         drain_b.dismiss();
         for (size_t c = 0; c < st.classes.size(); c++) {
@@ -1702,14 +1968,16 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare), and
-    //      pass 2: start positions.  Both are one launch per register bucket on the bucket's own lane, and a
-    //      bucket's start pass only reads end columns of the bucket's own pairs: the two follow each other in the
-    //      lane without a join in between, so one bucket's re-run rides under the other buckets' start passes. ----
-    {
+    //      pass 2: start positions. ----
+    const bool band_starts = ctx->cfg.banded_starts != 0 && st.total_loc > 0 && st.S + 1 <= 32;
+    if (!band_starts) {
+        // Full-height reverse pass: one launch per register bucket on the bucket's own lane.  A bucket's start pass
+        // only reads end columns of the bucket's own pairs, so the re-run and the start pass follow each other in
+        // the lane without a join in between: one bucket's re-run rides under the other buckets' start passes.
         ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
         for (int b = kBuckets - 1; b >= 0; b--) {
             if (h_overflow[b]) // only the buckets that have such a pair: an idle launch would still hold the bucket's lane
-                ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), st.buckets[b].n_fwd));
+                ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), h_rerun[b]));
             MyArgs ab = a;
             ab.n_rr = 0;
             int32_t blocks = 0;
@@ -1723,6 +1991,84 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             }
             st.buckets[b].n_rev = blocks;
             ULTRA_HIP_CHECK(ctx, launch_mega<MODE_REV>(ctx, ab, b, nullptr, blocks));
+        }
+        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    } else {
+        // Banded reverse pass, lane per location.  The locations are sorted by (band class, columns) so that the
+        // lanes of a wavefront run equally long; what no band class takes (2 x distance > 374) goes through the
+        // full-height kernels as dense per-size-class lists.
+        const size_t NL = (size_t)st.total_loc;
+        ULTRA_HIP_CHECK(ctx, st.startitems.ensure(NL * 4 * 4 + 64)); // keys in | keys out | locations in | locations out
+        ULTRA_HIP_CHECK(ctx, st.startinfo.ensure(256));
+        uint32_t *k_in = st.startitems.as<uint32_t>(), *k_out = k_in + NL;
+        int32_t *v_in = (int32_t *)(k_out + NL), *v_out = v_in + NL;
+        // the exact re-runs write end columns the start kernels read: they go first, beside the sort
+        ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+        for (int b = kBuckets - 1; b >= 0; b--)
+            if (h_overflow[b])
+                ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), h_rerun[b]));
+        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.startinfo.p, 0, 256, s));
+        hipLaunchKernelGGL(k_start_keys, dim3((unsigned)((NL + 255) / 256)), dim3(256), 0, s, a, (int64_t)NL, k_in, v_in);
+        {
+            size_t tmp_bytes = 0;
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, NL, 0, kBandLBits + 3, s));
+            ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, v_in, v_out, NL, 0, kBandLBits + 3, s));
+        }
+        hipLaunchKernelGGL(k_band_bounds, dim3(1), dim3(64), 0, s, k_out, (int64_t)NL, st.startinfo.as<int32_t>());
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+        int32_t h_info[kBandBounds];
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.startinfo.p, sizeof h_info, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        const int np = st.S + 1 <= 8 ? 3 : 5;
+        const int lanes = ctx->cfg.launch_lanes;
+        ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+        // full-height lists first (few, long wavefronts), on the lanes of their buckets
+        for (int b = kBuckets - 1; b >= 0; b--) {
+            MyArgs ab = a;
+            ab.rev_items = v_out;
+            ab.n_rr = 0;
+            int32_t blocks = 0;
+            for (int cls = kNumSizeClasses - 1; cls >= 0; cls--) {
+                if (bucket_of(cls) != b) continue;
+                const int64_t lb = h_info[kBandClasses + cls], le = h_info[kBandClasses + cls + 1];
+                if (le <= lb) continue;
+                const int per = 64 / kClasses[cls].G;
+                ab.rr[ab.n_rr].cls = cls; ab.rr[ab.n_rr].first_block = blocks; ab.rr[ab.n_rr].b = lb; ab.rr[ab.n_rr].e = le;
+                ab.n_rr++;
+                blocks += (int32_t)((le - lb + per - 1) / per);
+            }
+            st.buckets[b].n_rev = blocks;
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_REV>(ctx, ab, b, nullptr, blocks));
+        }
+        for (int c = kBandClasses - 1; c >= 0; c--) {
+            const int64_t ni = (int64_t)h_info[c + 1] - h_info[c];
+            if (ni <= 0) continue;
+            const int32_t *items = v_out + h_info[c];
+            const int64_t waves = (ni + 63) / 64;
+            const dim3 grid((unsigned)std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * 64)), block(64);
+            hipStream_t cs = ctx->lane(lanes > kBuckets ? kBuckets + c % (lanes - kBuckets) : c); // beside the buckets' full-height lists
+            const int WB = band_words(c);
+            if (c == 0) {
+                if (np == 3) hipLaunchKernelGGL((myers_bstart32<3>), grid, block, 0, cs, a, items, ni);
+                else hipLaunchKernelGGL((myers_bstart32<5>), grid, block, 0, cs, a, items, ni);
+            } else if (np == 3) {
+                switch (WB) {
+                case 1: hipLaunchKernelGGL((myers_bstart<1, 3>), grid, block, 0, cs, a, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_bstart<2, 3>), grid, block, 0, cs, a, items, ni); break;
+                case 4: hipLaunchKernelGGL((myers_bstart<4, 3>), grid, block, 0, cs, a, items, ni); break;
+                default: hipLaunchKernelGGL((myers_bstart<6, 3>), grid, block, 0, cs, a, items, ni); break;
+                }
+            } else {
+                switch (WB) {
+                case 1: hipLaunchKernelGGL((myers_bstart<1, 5>), grid, block, 0, cs, a, items, ni); break;
+                case 2: hipLaunchKernelGGL((myers_bstart<2, 5>), grid, block, 0, cs, a, items, ni); break;
+                case 4: hipLaunchKernelGGL((myers_bstart<4, 5>), grid, block, 0, cs, a, items, ni); break;
+                default: hipLaunchKernelGGL((myers_bstart<6, 5>), grid, block, 0, cs, a, items, ni); break;
+                }
+            }
+            ULTRA_HIP_CHECK(ctx, hipGetLastError());
         }
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }

@@ -41,7 +41,7 @@ class UltraError(RuntimeError):
 class Cfg(C.Structure):
     _fields_ = [("chain_switch_n", C.c_int32), ("overlap_small", C.c_int32), ("overlap_large", C.c_int32),
                 ("loc_slots", C.c_int32), ("banded_traceback", C.c_int32), ("nam_switch_n", C.c_int32),
-                ("launch_lanes", C.c_int32)]
+                ("launch_lanes", C.c_int32), ("banded_starts", C.c_int32)]
 
 
 _I32P, _I64P, _U8P, _F64P = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
