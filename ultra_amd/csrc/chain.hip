@@ -557,37 +557,52 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     // at the `small` instances and takes those that turn out tiny; chain_quadratic skips them
     const bool bounds_only = !nam && d_cnt != nullptr;
     const size_t n_tiny_launch = n_tiny + (bounds_only ? small.size() : 0);
-    if (n_tiny_launch > 0) {
-        a.thr = thr_s; a.list = d_list; a.nlist = (int32_t)n_tiny_launch; a.cap = (int32_t)n_tiny;
-        hipLaunchKernelGGL(chain_tiny, dim3((unsigned)((n_tiny_launch + 63) / 64)), dim3(64), 0, s, a);
-        ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    }
-    a.skip_tiny = bounds_only ? 1 : 0;
-    if (!small.empty()) {
-        a.thr = thr_s; a.list = d_list + n_tiny; a.nlist = (int32_t)small.size(); a.cap = kQuadSmall;
-        int blocks = ((int)small.size() + 3) / 4;
-        hipLaunchKernelGGL(chain_quadratic, dim3(blocks), dim3(256), (size_t)4 * kQuadSmall * qstride, s, a);
-        ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    }
-    a.skip_tiny = 0;
-    if (!big.empty()) {
-        a.thr = thr_s; a.list = d_list + n_tiny + small.size(); a.nlist = (int32_t)big.size(); a.cap = max_big;
-        size_t shmem = (size_t)max_big * qstride;
-        if (shmem > 64 * 1024)
-            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_quadratic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(chain_quadratic, dim3((unsigned)big.size()), dim3(64), shmem, s, a);
-        ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    }
-    if (!tree.empty()) {
+    // The launches work on disjoint instances and only read the inputs: dealt over the launch lanes so that the one or
+    // two wavefronts of the n log n solver (0.4 ms of critical path) and the lane-per-instance kernel run beside the
+    // quadratic solver instead of in front of and behind it.  Not with a caller's workspace: that entry point stays on
+    // the one stream it was given.
+    const int n_launch = (n_tiny_launch > 0) + !small.empty() + !big.empty() + !tree.empty();
+    const bool spread = !ws && ctx->cfg.launch_lanes > 1 && n_launch > 1;
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    int li = 0;
+    auto next_lane = [&]() { return spread ? ctx->lane(li++) : s; };
+    if (!tree.empty()) { // longest critical path first
+        hipStream_t cs = next_lane();
         a.thr = thr_l; a.list = d_list + n_tiny + small.size() + big.size(); a.nlist = (int32_t)tree.size(); a.cap = tree_leaves;
         a.work = ws ? ws->work : ch.work.as<uint8_t>(); a.work_off = d_workoff;
         const void *fn = nam ? (const void *)chain_nlogn<true> : (const void *)chain_nlogn<false>;
         if (tree_lds > 64 * 1024)
             ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
-        if (nam) hipLaunchKernelGGL(chain_nlogn<true>, dim3((unsigned)tree.size()), dim3(64), tree_lds, s, a);
-        else hipLaunchKernelGGL(chain_nlogn<false>, dim3((unsigned)tree.size()), dim3(64), tree_lds, s, a);
+        if (nam) hipLaunchKernelGGL(chain_nlogn<true>, dim3((unsigned)tree.size()), dim3(64), tree_lds, cs, a);
+        else hipLaunchKernelGGL(chain_nlogn<false>, dim3((unsigned)tree.size()), dim3(64), tree_lds, cs, a);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
+    a.skip_tiny = 0;
+    if (!big.empty()) {
+        hipStream_t cs = next_lane();
+        a.thr = thr_s; a.list = d_list + n_tiny + small.size(); a.nlist = (int32_t)big.size(); a.cap = max_big;
+        size_t shmem = (size_t)max_big * qstride;
+        if (shmem > 64 * 1024)
+            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_quadratic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(chain_quadratic, dim3((unsigned)big.size()), dim3(64), shmem, cs, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    a.skip_tiny = bounds_only ? 1 : 0;
+    if (!small.empty()) {
+        hipStream_t cs = next_lane();
+        a.thr = thr_s; a.list = d_list + n_tiny; a.nlist = (int32_t)small.size(); a.cap = kQuadSmall;
+        int blocks = ((int)small.size() + 3) / 4;
+        hipLaunchKernelGGL(chain_quadratic, dim3(blocks), dim3(256), (size_t)4 * kQuadSmall * qstride, cs, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    a.skip_tiny = 0;
+    if (n_tiny_launch > 0) {
+        hipStream_t cs = next_lane();
+        a.thr = thr_s; a.list = d_list; a.nlist = (int32_t)n_tiny_launch; a.cap = (int32_t)n_tiny;
+        hipLaunchKernelGGL(chain_tiny, dim3((unsigned)((n_tiny_launch + 63) / 64)), dim3(64), 0, cs, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     return ULTRA_OK;
 }
 
