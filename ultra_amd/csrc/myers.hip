@@ -666,12 +666,16 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
     if (MODE == MODE_FWD_EXACT) wi = list[a.wflag[blockIdx.x]]; // the forward launch over the same list left these
     else if (list) wi = list[blockIdx.x];
     else {
-        int r = 0;
-        while (r + 1 < a.n_rr && (int32_t)blockIdx.x >= a.rr[r + 1].first_block) r++;
-        wi.cls = a.rr[r].cls;
+        // constant indices only: a dynamically indexed member would move the whole argument block into scratch memory
+        int32_t cls = a.rr[0].cls, first = a.rr[0].first_block;
+        int64_t rb = a.rr[0].b, re = a.rr[0].e;
+#pragma unroll
+        for (int t = 1; t < 4; t++)
+            if (t < a.n_rr && (int32_t)blockIdx.x >= a.rr[t].first_block) { cls = a.rr[t].cls; first = a.rr[t].first_block; rb = a.rr[t].b; re = a.rr[t].e; }
+        wi.cls = cls;
         const int per = wi.cls < 4 ? 64 : wi.cls < 6 ? 32 : wi.cls < 8 ? 16 : wi.cls < 10 ? 8 : 1; // 64 / G of the class
-        wi.base = a.rr[r].b + (int64_t)((int32_t)blockIdx.x - a.rr[r].first_block) * per;
-        wi.end = a.rr[r].e;
+        wi.base = rb + (int64_t)((int32_t)blockIdx.x - first) * per;
+        wi.end = re;
         wi.cost = 0;
     }
     a.end = wi.end;
