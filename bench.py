@@ -285,37 +285,48 @@ def main():
             c.close()                       # the pipe's slots bring their own contexts
         ctxs = ctxs[:1]
         pipe = lib.Pipe(nix, local, depth=args.depth, cfg=cfg or None)
+        fields = ("nam_off", "nam_part", "nam_x", "nam_y", "reads", "read_off")
+        pageable = [tuple(getattr(rs, f) for f in fields) for rs in sets]
+        pins = [[lib.PinnedArray(getattr(rs, f)) for f in fields] for rs in sets]   # a caller that parses into page-locked buffers
+        pinned = [tuple(pa.a for pa in row) for row in pins]
 
-        def submit(b):
-            rs = sets[b % nb]
-            pipe.submit(rs.nam_off, rs.nam_part, rs.nam_x, rs.nam_y, rs.reads, rs.read_off, P["min_acc"])
-        for b in range(2 * args.depth):     # every slot allocates its buffers on its first batches
-            submit(b)
-            if pipe.pending() >= args.depth:
+        def run_e2e(batches, rounds):
+            def submit(b):
+                pipe.submit(*batches[b % nb], P["min_acc"])
+            for b in range(2 * args.depth):     # every slot allocates its buffers on its first batches
+                submit(b)
+                if pipe.pending() >= args.depth:
+                    pipe.wait(); pipe.release()
+            while pipe.pending():
                 pipe.wait(); pipe.release()
-        while pipe.pending():
-            pipe.wait(); pipe.release()
-        total = args.e2e_rounds * nb
-        sent = done = 0
-        tims, chains = [], 0
-        barrier()
-        t0 = time.perf_counter()
-        while done < total:
-            while sent < total and sent - done < args.depth:
-                submit(sent); sent += 1
-            r = pipe.wait()
-            chains += int(r["chain_off"][-1])
-            tims.append(pipe.timing())
-            pipe.release(); done += 1
-        barrier()
-        e2e_s = time.perf_counter() - t0
+            total = rounds * nb
+            sent = done = 0
+            tims, chains = [], 0
+            barrier()
+            t0 = time.perf_counter()
+            while done < total:
+                while sent < total and sent - done < args.depth:
+                    submit(sent); sent += 1
+                r = pipe.wait()
+                chains += int(r["chain_off"][-1])
+                tims.append(pipe.timing())
+                pipe.release(); done += 1
+            barrier()
+            secs = time.perf_counter() - t0
+            secs, n_reads, _ = shard.reduce_job(secs, args.reads * total, 0.0, device="cuda" if world > 1 else None)
+            avg = lambda k: sum(t[k] for t in tims) / len(tims)
+            return n_reads / secs, total, chains, {"stage_h2d_device_plan_sort": avg("stage_ms"), "waiting_for_gpu": avg("wait_ms"),
+                                                   "run": avg("run_ms"), "fetch_d2h": avg("fetch_ms")}
+        rate_pg, total, chains, ms_pg = run_e2e(pageable, args.e2e_rounds)
+        rate_pin, total, chains, ms_pin = run_e2e(pinned, args.e2e_rounds)
         pipe.close()
-        e2e_s, e2e_reads, _ = shard.reduce_job(e2e_s, args.reads * total, 0.0, device="cuda" if world > 1 else None)
-        avg = lambda k: sum(t[k] for t in tims) / len(tims)
-        e2e = {"reads_per_s": e2e_reads / e2e_s, "batches": total, "reads_per_batch": args.reads, "depth": args.depth,
-               "host_threads": args.depth, "input": "NAM chains + reads as flat host arrays (pageable)",
-               "output": "chains with kind / chromosome in pinned host memory", "per_batch_ms": {
-                   "stage_h2d_device_plan_sort": avg("stage_ms"), "waiting_for_gpu": avg("wait_ms"), "run": avg("run_ms"), "fetch_d2h": avg("fetch_ms")},
+        for row in pins:
+            for pa in row:
+                pa.close()
+        e2e = {"reads_per_s": rate_pin, "batches": total, "reads_per_batch": args.reads, "depth": args.depth,
+               "host_threads": args.depth, "input": "NAM chains + reads as flat arrays in page-locked host memory (ultra_host_alloc)",
+               "output": "chains with kind / chromosome in pinned host memory", "per_batch_ms": ms_pin,
+               "pageable_input": {"reads_per_s": rate_pg, "per_batch_ms": ms_pg},
                "chain_rows_fetched": chains,
                "synchronous_caller_reads_per_s": args.reads / ((restage_ms + elapsed / K * 1e3 + fetch_s * 1e3) * 1e-3)}
 

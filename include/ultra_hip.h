@@ -60,6 +60,11 @@ const char *ultra_last_error(const ultra_ctx *ctx);
 int ultra_device_count(void);
 /* name/CU count/clock of the ctx's device, for bench reports */
 int ultra_device_info(const ultra_ctx *ctx, char *name, int name_cap, int *n_cu, int *clock_khz);
+/* Page-locked host memory for a caller's input arrays (hipHostMalloc / hipHostFree).  Optional: every entry point takes
+ * ordinary memory too, but the copies of a batch to the device (NAM chains + reads, ~1.4 kB per read) only run at the
+ * link's rate and beside the caller's thread when they start in page-locked memory.  No reference counterpart. */
+int ultra_host_alloc(size_t bytes, void **out);
+void ultra_host_free(void *p);
 
 /*
  * Batched semi-global ("HW", infix) Myers bit-vector search with locations and first-location path

@@ -82,6 +82,19 @@ void ultra_ctx_destroy(ultra_ctx *ctx)
 
 const char *ultra_last_error(const ultra_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+int ultra_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return ULTRA_E_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return ULTRA_E_HIP; }
+    return ULTRA_OK;
+}
+
+void ultra_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int ultra_device_info(const ultra_ctx *ctx, char *name, int name_cap, int *n_cu, int *clock_khz)
 {
     if (!ctx) return ULTRA_E_ARG;

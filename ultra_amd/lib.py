@@ -19,7 +19,7 @@ _ERR_NAMES = {-1: "ULTRA_E_ARG", -2: "ULTRA_E_HIP", -3: "ULTRA_E_CAPACITY", -4: 
 
 EXPORTS = [
     "ultra_cfg_default", "ultra_ctx_create", "ultra_ctx_destroy", "ultra_last_error", "ultra_device_count",
-    "ultra_device_info", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
+    "ultra_device_info", "ultra_host_alloc", "ultra_host_free", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
     "ultra_myers_last_timing", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
     "ultra_chain_mams_batch_noalloc", "ultra_chain_noalloc_capacity",
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
@@ -105,6 +105,9 @@ def load():
     lib.ultra_last_error.restype = C.c_char_p
     lib.ultra_device_count.argtypes = []
     lib.ultra_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ultra_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.ultra_host_free.argtypes = [vp]
+    lib.ultra_host_free.restype = None
     lib.ultra_myers_hw_batch.argtypes = [vp, u8p, C.c_size_t, C.c_int32, i64p, i32p, i64p, i32p, i32p,
                                          i32p, i32p, i64p, i32p, i32p, C.c_int64, i64p, i32p, u8p, i64p, i32p]
     lib.ultra_myers_stage.argtypes = [vp, u8p, C.c_size_t, C.c_int32, i64p, i32p, i64p, i32p, i32p]
@@ -470,6 +473,39 @@ class Context(object):
                                                     _ptr(d, C.c_int32), None if mi is None else _ptr(mi, C.c_int64), solver,
                                                     _ptr(Cv, C.c_int64), _ptr(tr, C.c_int32), _ptr(value, C.c_int64)))
         return Cv[:len(c) + ni], tr[:len(c) + ni], value[:ni]
+
+
+class PinnedArray(object):
+    """A numpy array in page-locked host memory (ultra_host_alloc): `.a` is the array; free with close()."""
+
+    def __init__(self, src=None, shape=None, dtype=None):
+        so = load()
+        if src is not None:
+            src = np.ascontiguousarray(src)
+            shape, dtype = src.shape, src.dtype
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        rc = so.ultra_host_alloc(max(n, 1), C.byref(p))
+        if rc != 0 or not p.value:
+            raise MemoryError("ultra_host_alloc(%d) failed" % n)
+        self._so, self._p = so, p
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        if src is not None:
+            self.a[...] = src
+
+    def close(self):
+        if self._p is not None:
+            self.a = None
+            self._so.ultra_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Pipe(object):
