@@ -159,6 +159,23 @@ __device__ __forceinline__ void word_step(uint64_t &Pv, uint64_t &Mv, uint64_t E
     Mv = pack64(psl & xvl, psh & xvh);                                 // Mv' = Ph & Xv
 }
 
+// The same step for a FIRST word of the forward pass whose lower 32 rows are all top padding: those rows match
+// everything, carry no vertical delta and, in the HW forward pass, no horizontal one (the top boundary is 0), so they
+// stay as they are and only the upper half is computed: 12 instructions instead of 23.
+__device__ __forceinline__ void word_step_hi(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t &hp, uint32_t &hm)
+{
+    const uint32_t pvh = (uint32_t)(Pv >> 32), mvh = (uint32_t)(Mv >> 32), eqh = (uint32_t)(Eq >> 32);
+    const uint32_t xvh = eqh | mvh;
+    const uint32_t sum = (eqh & pvh) + pvh;
+    const uint32_t xhh = bop3<0xBE>(sum, pvh, eqh);
+    const uint32_t phh = bop3<0xF1>(mvh, xhh, pvh);
+    const uint32_t mhh = pvh & xhh;
+    const uint32_t psh = phh << 1, msh = mhh << 1;
+    hp = phh >> 31; hm = mhh >> 31;
+    Pv = pack64((uint32_t)Pv, bop3<0xF1>(msh, xvh, psh));
+    Mv = pack64((uint32_t)Mv, psh & xvh);
+}
+
 __device__ __forceinline__ uint64_t pad_mask(int pad, int blk) // bits of word blk whose global row index < pad
 {
     int r = pad - 64 * blk;
@@ -322,7 +339,7 @@ __device__ __forceinline__ void traceback_group(const ulonglong2 *tr, int nbb, i
 // ------------------------------------------------------------------------------------------------
 // One wavefront's worth of work: items [base, base + 64) (clipped to a.end).  lds_wave: S*W*64 words
 // private to the wavefront; gwave: index of the wavefront's trace region (MODE_NW only).
-template <int W, int MODE>
+template <int W, int MODE, bool HALF = false>
 __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_t *lds_wave, int64_t gwave)
 {
     const int lane = threadIdx.x & 63;
@@ -400,6 +417,7 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
 #pragma unroll
                     for (int b = 0; b < W; b++) {
                         uint64_t ph0;
+                        if (FWD && HALF && b == 0) { word_step_hi(Pv[0], Mv[0], eq[0], hp, hm); continue; } // HALF: see lane_forward
                         word_step(Pv[b], Mv[b], eq[b], hp, hm, ph0);
                         if (MODE == MODE_NW) {
                             ulonglong2 e; e.x = Pv[b]; e.y = ph0;
@@ -463,6 +481,18 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
             __threadfence();
         }
     }
+}
+
+// Forward pass of a lane class: when every pair of the wavefront leaves the lower half of its first word to the top
+// padding (the pairs are sorted for that: k_pair_keys), that word runs on one 32-bit half.  Decided once per work item,
+// outside every loop, so that each variant keeps its own instruction schedule and register allocation.
+template <int W, int MODE>
+__device__ __forceinline__ void lane_forward(const MyArgs &a, int64_t base, uint64_t *lds_wave)
+{
+    const int64_t p = base + (threadIdx.x & 63);
+    const int m = p < a.end ? a.q_len[p] : 1;
+    if (__builtin_amdgcn_readfirstlane((int)(__all(64 * W - m >= 32) ? 1 : 0)) != 0) lane_item<W, MODE, true>(a, base, lds_wave, 0);
+    else lane_item<W, MODE, false>(a, base, lds_wave, 0);
 }
 
 template <int W, int MODE>
@@ -679,10 +709,13 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
         wi.cost = 0;
     }
     a.end = wi.end;
+    constexpr bool FWD = MODE == MODE_FWD || MODE == MODE_FWD_EXACT;
     if (BUCKET == 0) {
-        if (wi.cls == 0) lane_item<1, MODE>(a, wi.base, lds, 0); else lane_item<2, MODE>(a, wi.base, lds, 0);
+        if (FWD) { if (wi.cls == 0) lane_forward<1, MODE>(a, wi.base, lds); else lane_forward<2, MODE>(a, wi.base, lds); }
+        else if (wi.cls == 0) lane_item<1, MODE>(a, wi.base, lds, 0); else lane_item<2, MODE>(a, wi.base, lds, 0);
     } else if (BUCKET == 1) {
-        if (wi.cls == 2) lane_item<3, MODE>(a, wi.base, lds, 0); else lane_item<4, MODE>(a, wi.base, lds, 0);
+        if (FWD) { if (wi.cls == 2) lane_forward<3, MODE>(a, wi.base, lds); else lane_forward<4, MODE>(a, wi.base, lds); }
+        else if (wi.cls == 2) lane_item<3, MODE>(a, wi.base, lds, 0); else lane_item<4, MODE>(a, wi.base, lds, 0);
     } else if (BUCKET == 2) {
         if (wi.cls == 4) group_item<2, 3, MODE>(a, wi.base, lds, 0); else group_item<2, 4, MODE>(a, wi.base, lds, 0);
     } else if (BUCKET == 3) {
@@ -1629,7 +1662,10 @@ __global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const i
     if (p < n) {
         const int m = q_len[p], t = t_len[p];
         const uint32_t c = size_class_of(m);
-        keys[p] = (c << 24) | (uint32_t)(t < 0xFFFFFF ? t : 0xFFFFFF);
+        // Lane classes (m <= 256): queries that leave the lower half of their first word empty sort together, so that
+        // whole wavefronts can run that word on one 32-bit half (lane_forward).
+        const uint32_t half = (c < 4 && ((c + 1) * 64 - (uint32_t)m) >= 32) ? 1u : 0u;
+        keys[p] = (c << 25) | (half << 24) | (uint32_t)(t < 0xFFFFFF ? t : 0xFFFFFF);
         idx[p] = p;
         atomicAdd(&sh[c], 1ull);
         atomicAdd(&sh[kNumSizeClasses + c], (unsigned long long)m * (unsigned long long)t);
@@ -1733,9 +1769,9 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
                        st.stats.as<unsigned long long>());
     {
         size_t tmp_bytes = 0;
-        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 28, s));
+        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 29, s));
         ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
-        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 28, s));
+        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 29, s));
     }
     hipLaunchKernelGGL(k_gather_pairs, dim3(gp), dim3(256), 0, s, st.perm_d.as<int32_t>(), n_pairs, (int64_t)kArenaPad,
                        st.u_qoff.as<int64_t>(), st.u_qlen.as<int32_t>(), st.u_toff.as<int64_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(),
