@@ -33,15 +33,18 @@ def main():
     dominant = sys.argv[5] if len(sys.argv) > 5 else None
     rows = list(csv.DictReader(open(stats)))
     f, w = counters(fetch), counters(write)
-    out = {"tag": tag, "kernels": []}
+    import datetime
+    out = {"tag": tag, "recorded": datetime.date.today().isoformat(),
+           "command": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, GPU_MAX_HW_QUEUES=8) -- "
+                      "python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --check 0 --e2e-rounds 0 --micro 0 (scripts/profile_round.sh)",
+           "kernels": []}
     for r in rows:
         k = short(r["Name"])
         out["kernels"].append({"kernel": k, "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"]),
                                "fetch_kb_raw": f.get(k), "write_kb": w.get(k)})
     if dominant is None:
-        fw = [k for k in out["kernels"] if k["kernel"].startswith("myers_lane<") and k["kernel"].endswith(", 0>")
-              or k["kernel"].startswith("myers_group<") and k["kernel"].endswith(", 0>")]
+        fw = [k for k in out["kernels"] if k["kernel"].startswith("myers_mega<0,")]
         dominant = max(fw, key=lambda k: k["total_ms"])["kernel"]
     d = [k for k in out["kernels"] if k["kernel"] == dominant][0]
     out["dominant_kernel"] = dominant
@@ -58,7 +61,7 @@ def main():
     with open(os.path.join(ROOT, "profiles", "%s_summary.json" % tag), "w") as fh:
         json.dump(out, fh, indent=1)
     with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as fh:
-        json.dump({k: out[k] for k in ("tag", "dominant_kernel", "dominant_avg_us", "hbm_bytes_per_launch",
+        json.dump({k: out[k] for k in ("tag", "recorded", "command", "dominant_kernel", "dominant_avg_us", "hbm_bytes_per_launch",
                                       "hbm_bytes_per_launch_raw_counters", "forward_family")}, fh, indent=1)
     print(dominant, d["avg_us"], out["hbm_bytes_per_launch"])
 
