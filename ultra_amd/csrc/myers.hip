@@ -791,17 +791,23 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
         const int hh = (ed - (delta < 0 ? -delta : delta)) >> 1;
         const int off = ((delta < 0 ? delta : 0) - hh - 1 + TOP) & ~7;
         uint64_t PL[NP][WB], VP[WB], VN[WB];
-        // Target and query bytes, eight at a time.  Column c consumes target byte c and query row TOP + 1 + off + c
-        // (both multiples of 8 together), so one prefetch fetches the two 8-byte blocks a group of eight columns
-        // starts with; it is issued a whole group ahead (these kernels run at one or two wavefronts per SIMD:
-        // nothing else hides a load).
-        uint64_t qw = 0, tw = 0, qwn = 0, twn = 0;
-        int pref_c = -0x40000000; // column group the blocks in twn / qwn belong to
+        // Target and query bytes travel one chunk of K columns at a time (K / 8 loads of 8 bytes each, issued together
+        // a whole chunk before their first use; see myers_band32).  Column c consumes target byte c and query row
+        // TOP + 1 + off + c, both multiples of 8 together.  These kernels run at one or two wavefronts per SIMD:
+        // nothing else hides a load.
+        constexpr int NB = K / 8;
+        uint64_t qw = 0, tw = 0, qwb[NB], twb[NB], qwn[NB], twn[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) { qwb[i] = twb[i] = qwn[i] = twn[i] = 0; }
+        int pref_c = -0x40000000; // chunk the blocks in twn / qwn belong to
         auto qblock = [&](int r) { return (r >= 0 && r < m) ? load8(q + r) : (uint64_t)0; };
         auto prefetch = [&](int cn) {
             pref_c = cn;
-            twn = (cn >= 0 && cn < L) ? load8(t + cn) : 0;
-            qwn = qblock(TOP + 1 + off + cn);
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                twn[i] = (cn + 8 * i >= 0 && cn + 8 * i < L) ? load8(t + cn + 8 * i) : 0;
+                qwn[i] = qblock(TOP + 1 + off + cn + 8 * i);
+            }
         };
         auto push_row = [&](uint32_t code1) { // code + 1 of the row entering at the bottom; 0 = outside the query: matches nothing
 #pragma unroll
@@ -814,11 +820,13 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
         // one column of the banded recurrence; STORE: leave {Pv, Ph} of the column in LDS slot k.
         // next_c: the column group to prefetch when this column opens a group
         auto column = [&](int c, int k, bool store, int next_c) {
-            if ((c & 7) == 0) {
-                if (pref_c != c) prefetch(c); // not staged ahead: first group of a sweep, or chunks were skipped
-                tw = twn; qw = qwn;
+            if (k == 0) { // k is a compile-time constant in the unrolled chunk loops
+                if (pref_c != c) prefetch(c); // not staged ahead: first chunk of a sweep, or chunks were skipped
+#pragma unroll
+                for (int i = 0; i < NB; i++) { twb[i] = twn[i]; qwb[i] = qwn[i]; }
                 prefetch(next_c);
             }
+            if ((k & 7) == 0) { tw = twb[k >> 3]; qw = qwb[k >> 3]; }
             const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
             tw >>= 8;
             // match vector: bit set where every plane of the query code equals the target's bit (XNOR per plane,
@@ -906,7 +914,8 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
                     for (int w = 0; w < WB; w++) cp[((2 + k) * WB + w) * 64] = PL[k][w];
             }
             if (h + 1 < nchunk) // the last chunk is recomputed first anyway
-                for (int k = 0; k < K; k++) column(h * K + k, k, false, h * K + k + 8);
+#pragma unroll
+                for (int k = 0; k < K; k++) column(h * K + k, k, false, h * K + K);
         }
         // ---- backwards through the chunks: recompute into LDS, walk inside LDS ----
         int r = m - 1, c = L - 1, ins = 0;
@@ -925,7 +934,8 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
                     for (int w = 0; w < WB; w++) PL[k][w] = cp[((2 + k) * WB + w) * 64];
             }
             // next group in processing order: the rest of this chunk, then the chunk before it
-            for (int k = 0; k < K; k++) column(c0 + k, k, true, k + 8 < K ? c0 + k + 8 : c0 - K);
+#pragma unroll
+            for (int k = 0; k < K; k++) column(c0 + k, k, true, c0 - K);
             if (act) {
                 while (r >= 0 && c >= c0) {
                     const int b = r - c + TOP - off;
