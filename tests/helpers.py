@@ -209,3 +209,21 @@ def simulate_transcript_reads(exons, refs, rng, n):
         qual = "".join(chr(33 + int(q)) for q in rng.randint(2, 40, len(seq))) if i % 3 == 0 else None
         reads.append(("sim%d_%s" % (i, tid), seq, qual))
     return reads
+
+
+# ---- picklable stand-ins for the stages behind the MAM stage (the pc.main test starts consumer PROCESSES) ----
+def stub_find_exons(chr_id, mam_solution, ref_exon_sequences, ref_segment_sequences, ref_flank_sequences, splice_pairs):
+    from array import array
+    exons = [(m.x, m.y, m.c, m.d, m.ref_chr_id) for m in mam_solution]
+    seq = "".join(ref_segment_sequences.get(array('L', [m.ref_chr_id, m.x, m.y]).tobytes(), "") for m in mam_solution)
+    pred = [(m.x, m.y) for m in mam_solution]
+    splices = [(a[1], b[0]) for a, b in zip(pred[:-1], pred[1:])]
+    return exons, seq, pred, splices, sum(m.d - m.c + 1 for m in mam_solution)
+
+
+def stub_classify(chr_id, splices, *rest):
+    return ("NO_SPLICE", "") if not splices else ("FSM" if len(splices) % 2 else "NIC_novel", "tr%d" % len(splices))
+
+
+def stub_sam_entry(*a, **kw):
+    return "\t".join(str(v) for v in a) + "\t" + str(sorted(kw.items())) + "\n"

@@ -205,3 +205,52 @@ def test_align_single_equals_the_reference_on_sirv(ctx, tmp_path, gpu_batch):
         state.close()
     # every recorded SAM row and alignment was needed by one of the two runs
     assert used["sam_entry"] == set(calls["sam_entry"]) and used["exact_alignment"] == set(calls["exact_alignment"])
+
+
+def test_pc_main_runs_the_reference_protocol(ctx, tmp_path):
+    """ultra_amd.pc.main(reads, seeds, outfile, args) as uLTRA:382 calls it: a producer zipping the reads file with the
+    seed file into 1000-read queue batches, one align_single consumer PROCESS per GPU reading the index pickles from
+    args.outfolder, SAM rows appended to the output file, the 8-entry totals returned.  Same rows as align_single run
+    in this process on the same records (base-level alignment on the GPU in both)."""
+    from tests import helpers
+    from ultra_amd import align, indexer, pc, seed_wrapper, seeder
+    here = os.path.dirname(os.path.abspath(__file__))
+    sirv = os.path.join(here, "golden", "sirv")
+    out = str(tmp_path)
+    ann = indexer.build_index(os.path.join(sirv, "SIRV_genes_C_170612a.gtf"), os.path.join(sirv, "SIRV_genes.fasta"), out)
+    refs = indexer.read_fasta(os.path.join(sirv, "SIRV_genes.fasta"))
+    rng = np.random.RandomState(5)
+    reads = helpers.simulate_transcript_reads(indexer.read_gtf(os.path.join(sirv, "SIRV_genes_C_170612a.gtf")), refs, rng, 2300)
+    reads_path, seeds_path, sam_path = os.path.join(out, "reads.fq"), os.path.join(out, "seeds.txt.gz"), os.path.join(out, "reads.sam")
+    with open(reads_path, "w") as fh:
+        for acc, seq, qual in reads:
+            fh.write("@%s\n%s\n+\n%s\n" % (acc, seq, qual) if qual else ">%s\n%s\n" % (acc, seq))
+    seeder.write_seed_file(seeds_path, [(a, s) for a, s, _ in reads], ann["ref_part_sequences"], min_len=15)
+    open(sam_path, "w").close()
+    down = align.Downstream(helpers.stub_find_exons, helpers.stub_classify, None, helpers.stub_sam_entry)
+    args = types.SimpleNamespace(outfolder=out, index=out, reduce_read_ployA=20, max_intron=1200000, dropoff=0.95, max_loc=5, min_acc=0.6,
+                                 alignment_threshold=0.5, non_covered_cutoff=15, gpus=1, gpu_batch_reads=1500, downstream=down)
+    totals = pc.main(reads_path, seeds_path, sam_path, args)
+    rows = open(sam_path).read().splitlines(True)
+    # the same records through align_single in this process
+    with open(reads_path) as fh:
+        records = [[acc, seq, qual, hits, hits_rc] for (acc, (seq, qual)), (_, hits, _, hits_rc) in zip(pc.readfq(fh), seed_wrapper.read_seeds(seeds_path))]
+    assert [r[0] for r in records] == [a for a, _, _ in reads] and [r[2] for r in records] == [q for _, _, q in reads]
+    state = align.AlignState(indexer.align_data(ann), ctx=ctx, device=0)
+    try:
+        args2 = types.SimpleNamespace(**dict(vars(args), ultra_state=state, gpu_batch_reads=65536))
+        qin, qout, qcnt = queue.Queue(), queue.Queue(), queue.Queue()
+        for b in range(0, len(records), 1000):
+            qin.put([b // 1000 + 1, records[b:b + 1000]])
+        qin.put(None)
+        align.align_single(0, qin, qout, qcnt, args2)
+        want = []
+        while not qout.empty():
+            want.extend(qout.get())
+        counts = qcnt.get()
+    finally:
+        state.close()
+    assert len(rows) == len(want) >= len(reads)
+    assert sorted(rows) == sorted(want)                 # batches come back in completion order
+    assert totals[1:] == counts[1:] and abs(totals[0] - counts[0]) < 1e-6
+    assert sum(totals[1:]) > len(reads) // 2
