@@ -133,12 +133,14 @@ def test_banded_and_full_height_traceback_agree(ctx):
     try:
         for qr, tr, n, rates in [((9, 300), (100, 900), 1500, (0.0, 0.05, 0.2, 0.35)),
                                  ((300, 1400), (400, 2000), 200, (0.02, 0.1, 0.2)),
-                                 ((1300, 1900), (1500, 2600), 60, (0.3, 0.36))]:   # distances beyond every band class
+                                 ((1300, 1900), (1500, 2600), 60, (0.3, 0.36)),    # the 8-, 12- and 16-word bands (lane groups)
+                                 ((3600, 4400), (3800, 5200), 20, (0.36, 0.39))]:  # distances beyond every band class (> 1014)
             pairs = helpers.make_pairs(rng, n, qr, tr, kmode="ref", planted=0.9, rates=rates)
             a = _check(ctx, pairs)
             b = _check(full, pairs)
             assert np.array_equal(a["first_ins"], b["first_ins"])
             assert (a["ed"] > 374).any() or qr[0] < 1300
+            assert (a["ed"] > 1014).any() or qr[0] < 3600
     finally:
         full.close()
 
@@ -152,7 +154,8 @@ def test_banded_traceback_wide_alphabet(ctx):
 def test_banded_traceback_skewed_paths(ctx, mix):
     """The band is shifted per pair towards the diagonals its path can reach (end diagonal m - L): deletion-only,
     insertion-only and long contiguous gaps put the path far from the main diagonal, and the rates make the
-    distances straddle every band-class limit (22, 54, 118, 246, 374)."""
+    distances straddle the band-class limits (22, 54, 118, 246, 374; 502, 758, 1014 are covered by
+    test_banded_and_full_height_traceback_agree and test_wide_lane_group_bands)."""
     rng = np.random.RandomState(13 + int(mix[0] * 10) + int(mix[2] * 100))
     for qr, tr, n, rates, block in [((9, 260), (100, 900), 1200, (0.05, 0.2, 0.3, 0.38), 0),
                                     ((100, 400), (300, 1000), 500, (0.1, 0.2, 0.3), 60),
@@ -193,3 +196,21 @@ def test_banded_and_full_height_start_pass_agree(ctx):
         assert (a["n_loc"] >= 1).any()
     finally:
         full.close()
+
+
+@pytest.mark.parametrize("mix", [(0.5, 0.3, 0.2), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0)])
+def test_wide_lane_group_bands(ctx, mix):
+    """The band classes of 4 to 16 words run with 2 to 8 lanes per hit (myers_bandg): distances on either side of
+    246, 374, 502, 758 and 1014, balanced / deletion-only / insertion-only edits and long contiguous gaps, several
+    hits per wavefront and wavefronts that are not full."""
+    rng = np.random.RandomState(31 + int(mix[0] * 10) + int(mix[2] * 100))
+    seen = set()
+    for qr, tr, n, rates, block in [((700, 1400), (900, 2600), 150, (0.2, 0.28, 0.36), 0),
+                                    ((1500, 2600), (1800, 3600), 70, (0.12, 0.2, 0.3, 0.38), 300),
+                                    ((2400, 3000), (2600, 4000), 23, (0.2, 0.3, 0.36), 0)]:
+        got = _check(ctx, helpers.make_pairs(rng, n, qr, tr, kmode="ref", planted=0.95, rates=rates, mix=mix, block=block))
+        ed = got["ed"][got["ed"] >= 0]
+        for lim in (246, 374, 502, 758, 1014):
+            if (ed <= lim).any() and (ed > lim).any():
+                seen.add(lim)
+    assert {374, 502} <= seen and (758 in seen or mix[0] == 1.0)   # deletions alone stay below 758 at these lengths

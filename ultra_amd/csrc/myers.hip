@@ -27,12 +27,14 @@
 namespace {
 
 enum { MODE_FWD = 0, MODE_FWD_EXACT = 1, MODE_REV = 2, MODE_NW = 3 };
-enum { kBandClasses = 5, kBandFallback = 5 }; // banded traceback: 32 rows, then WB = 1, 2, 4, 6 words; class 5 = not banded
-// A lane-per-hit band kernel is bound by its longest lane (words x columns, twice): 6 words cover all but a
-// handful of hits per batch, and those few are quicker through the lane-group full-height kernels than through
-// an 8-word band.  Most hits need far less than one word (distance <= 22): they get a 32-row band of their own,
-// half the arithmetic, checkpoint bytes and LDS of the 1-word band (myers_band32).
-__host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : 6; } // classes 1..4
+enum { kBandClasses = 8, kBandFallback = 8 }; // banded traceback: 32 rows, then WB = 1, 2, 4, 6, 8, 12, 16 words; class 8 = not banded
+// A lane-per-hit band kernel is bound by its longest lane (words x columns, twice): up to 2 words a hit keeps a lane
+// to itself (myers_band, and myers_band32 for the 86 % of hits with distance <= 22: half the arithmetic, checkpoint
+// bytes and LDS of the 1-word band); from 4 words on the window is split over 2 - 8 neighbouring lanes (myers_bandg),
+// which is also what lets the band reach 16 words (distance <= 1014) before the full-height kernels take over (a
+// 24-word class over 8 lanes measured slower than those for the few hits beyond).
+__host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : 16; } // classes 1..7
+__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 2 : c == 4 ? 3 : c == 5 ? 4 : c == 6 ? 4 : 8; }    // lanes per hit
 __host__ __device__ constexpr int band_rows(int c) { return c == 0 ? 32 : 64 * band_words(c); }
 __host__ __device__ constexpr int band_chunk(int c) { return c == 0 ? 32 : c == 1 ? 16 : 8; } // columns per checkpoint
 
@@ -950,6 +952,236 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
         }
         if (valid) {
             if (r >= 0) ins += r + 1; // target used up: the remaining query bases are insertions
+            a.first_ins[p] = ins;
+        }
+    }
+}
+
+// The wide classes with G lanes per hit: the window's 64*WB rows are split over G neighbouring lanes (WBL words
+// each, lane g of a hit holds words g*WBL ..), so a column costs a lane 1/G of the instructions, the critical path
+// of a launch - its longest hit, twice - shrinks accordingly, and bands far wider than a lane's registers hold
+// become possible (16 words: distances up to 1014, the long reads contained in long exons that otherwise take the
+// full-height kernels with their whole-matrix trace).  What crosses lanes per column: the carry of the one addition
+// (each lane adds with carry-in 0 and reports carry-out and "all ones"; a lane's carry-in follows from the two
+// wave-wide ballots: the nearest lower lane of the group that generates or stops a carry decides), and the bits that
+// shift in from the lane above (D0, Ph, the bit-planes).  All lanes of a hit walk the same path (the stored columns
+// are in LDS, any lane reads any lane's words); lane 0 of the group reports.  Cross-lane reads are never executed
+// under a lane-dependent condition: the source lane would be inactive.
+template <int G, int WBL, int NP>
+__global__ void __launch_bounds__(64) myers_bandg(MyArgs a, const int32_t *items, int64_t n_items)
+{
+    constexpr int WB = G * WBL;
+    constexpr int TOP = 32 * WB - 1;
+    constexpr int K = 8;
+    constexpr int HITS = 64 / G;                // hits per wavefront (G = 3: lane 63 idles)
+    constexpr int CPW = (2 + NP) * WBL;         // 64-bit words per checkpoint and lane
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x;
+    const int g = lane % G, h = lane / G;
+    const uint64_t below_me = (lane == 0 ? 0ull : (~0ull >> (64 - lane))) & ~((lane - g) == 0 ? 0ull : (~0ull >> (64 - (lane - g)))); // lanes of my hit below me
+    const int64_t gwave = blockIdx.x, nwaves = gridDim.x;
+    uint64_t *CP = (uint64_t *)a.tr + gwave * a.region + lane; // checkpoint (chunk c, word f) at CP[(c * CPW + f) * 64]
+    extern __shared__ ulonglong2 band_lds[];
+    ulonglong2 *col = band_lds; // (column k of the chunk, word w of lane l) at col[(k * WBL + w) * 64 + l]
+    for (int64_t base = gwave * HITS; base < n_items; base += nwaves * HITS) {
+        const bool valid = h < HITS && base + h < n_items;
+        int p = 0, m = 0, L = 0, ed = 0;
+        const uint8_t *q = a.seq, *t = a.seq;
+        if (valid) {
+            p = items[base + h];
+            m = a.q_len[p];
+            ed = a.ed[p];
+            const int64_t lo = a.loc_off[p];
+            const int s0 = a.loc_start[lo];
+            L = a.loc_end[lo] - s0 + 1;
+            q = a.seq + a.q_off[p];
+            t = a.seq + a.t_off[p] + s0;
+        }
+        const int delta = m - L;
+        const int hh = (ed - (delta < 0 ? -delta : delta)) >> 1;
+        const int off = ((delta < 0 ? delta : 0) - hh - 1 + TOP) & ~7; // see myers_band
+        uint64_t PL[NP][WBL], VP[WBL], VN[WBL];
+        uint64_t qw = 0, tw = 0, qwn = 0, twn = 0;
+        int pref_c = -0x40000000;
+        auto qblock = [&](int r) { return (r >= 0 && r < m) ? load8(q + r) : (uint64_t)0; };
+        auto prefetch = [&](int cn) {
+            pref_c = cn;
+            twn = (cn >= 0 && cn < L) ? load8(t + cn) : 0;
+            qwn = qblock(TOP + 1 + off + cn);
+        };
+        // value of lane + 1 as a DPP move (a VALU instruction, not a trip through the LDS crossbar): groups of 2, 4 and 8
+        // lanes never straddle a row of 16, groups of 3 do
+        auto from_next_lane = [&](int v) {
+            return G == 3 ? __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
+                          : __builtin_amdgcn_update_dpp(0, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+        };
+        auto push_row = [&](uint32_t code1) { // the whole window moves down one row; the top lane takes the new row's code
+            uint32_t low = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) low |= ((uint32_t)PL[k][0] & 1u) << k;
+            const uint32_t above = (uint32_t)from_next_lane((int)low); // bit 0 of the next lane's planes, before they move
+            const uint32_t in = g == G - 1 ? code1 : above;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+#pragma unroll
+                for (int w = 0; w < WBL - 1; w++) PL[k][w] = shr1_in(PL[k][w], (uint32_t)PL[k][w + 1]);
+                PL[k][WBL - 1] = shr1_in(PL[k][WBL - 1], in >> k);
+            }
+        };
+        auto column = [&](int c, int k, bool store, int next_c) {
+            if (k == 0) {
+                if (pref_c != c) prefetch(c);
+                tw = twn; qw = qwn;
+                prefetch(next_c);
+            }
+            const uint32_t tc1 = (uint32_t)(tw & 0xff) + 1u;
+            tw >>= 8;
+            uint64_t Eq[WBL];
+            {
+                uint32_t mk[NP];
+#pragma unroll
+                for (int kk = 0; kk < NP; kk++) mk[kk] = ((tc1 >> kk) & 1u) - 1u;
+#pragma unroll
+                for (int w = 0; w < WBL; w++) {
+                    uint32_t el = (uint32_t)PL[0][w] ^ mk[0], eh = (uint32_t)(PL[0][w] >> 32) ^ mk[0];
+#pragma unroll
+                    for (int kk = 1; kk < NP; kk++) {
+                        el = bop3<0x60>(el, (uint32_t)PL[kk][w], mk[kk]);
+                        eh = bop3<0x60>(eh, (uint32_t)(PL[kk][w] >> 32), mk[kk]);
+                    }
+                    Eq[w] = pack64(el, eh);
+                }
+            }
+            // (Eq & VP) + VP over the whole window: first with carry-in 0 per lane ...
+            uint64_t SUM[WBL];
+            uint64_t carry = 0, ones = ~(uint64_t)0;
+#pragma unroll
+            for (int w = 0; w < WBL; w++) {
+                const uint64_t x = Eq[w] & VP[w];
+                const uint64_t s1 = x + VP[w];
+                const uint64_t s2 = s1 + carry;
+                carry = (uint64_t)((s1 < x) | (s2 < s1));
+                SUM[w] = s2;
+                ones &= s2;
+            }
+            // ... then the carry-in: the nearest lower lane of the hit that generates a carry (1) or stops one (0)
+            {
+                const uint64_t gen = __ballot(carry != 0);
+                const uint64_t pass = __ballot(ones == ~(uint64_t)0);
+                const uint64_t decides = (gen | ~pass) & below_me;
+                uint64_t cin = 0;
+                if (decides) cin = (gen >> (63 - __clzll((long long)decides))) & 1ull;
+#pragma unroll
+                for (int w = 0; w < WBL; w++) {
+                    const uint64_t sx = SUM[w] + cin;
+                    cin = (uint64_t)(sx < cin);
+                    SUM[w] = sx;
+                }
+            }
+            uint64_t D0[WBL], HP[WBL], HN[WBL];
+#pragma unroll
+            for (int w = 0; w < WBL; w++) {
+                D0[w] = bop3_64<0xBE>(SUM[w], VP[w], Eq[w]) | VN[w];
+                HP[w] = bop3_64<0xF1>(VN[w], D0[w], VP[w]);
+                HN[w] = D0[w] & VP[w];
+            }
+            // bit 0 of D0 and HP of the lane above shift into this lane's top word (nothing above the window)
+            const int lowbits = (int)(((uint32_t)D0[0] & 1u) | (((uint32_t)HP[0] & 1u) << 1));
+            const int from_above = from_next_lane(lowbits);
+            const int up = g == G - 1 ? 0 : from_above;
+#pragma unroll
+            for (int w = 0; w < WBL; w++) {
+                const uint64_t X = shr1_in(D0[w], w + 1 < WBL ? (uint32_t)D0[w + 1] : (uint32_t)(up & 1));
+                VN[w] = X & HP[w];
+                VP[w] = bop3_64<0xF1>(HN[w], X, HP[w]);
+                if (store) {
+                    ulonglong2 e; e.x = VP[w];
+                    e.y = shr1_in(HP[w], w + 1 < WBL ? (uint32_t)HP[w + 1] : (uint32_t)((up >> 1) & 1));
+                    col[(k * WBL + w) * 64 + lane] = e;
+                }
+            }
+            {
+                const int r = TOP + 1 + off + c;
+                push_row((r >= 0 && r < m) ? (uint32_t)(qw & 0xff) + 1u : 0u);
+                qw >>= 8;
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < NP; k++)
+#pragma unroll
+            for (int w = 0; w < WBL; w++) PL[k][w] = 0;
+        {
+            // every lane of the wavefront takes part in push_row's exchange the same number of times: the rows a
+            // lane pushes beyond its own are virtual (above row 0) and fall out of the window again
+            const int r_end = TOP + 1 + off, r0 = off - TOP - 1;
+            const int mine = r0 < 0 ? (r_end < 0 ? r_end : 0) : r0;
+            const int steps = wave_max_i32(r_end - mine);
+            int ri = r_end - steps; // a multiple of 8, never below the window's first row
+            uint64_t cur = 0, nxt = qblock(ri);
+            for (int sidx = 0; sidx < steps; sidx++) {
+                if ((ri & 7) == 0) { cur = nxt; nxt = qblock(ri + 8); }
+                push_row((ri >= 0 && ri < m) ? (uint32_t)(cur & 0xff) + 1u : 0u);
+                cur >>= 8;
+                ri++;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < WBL; w++) {
+            const int z = TOP + 1 - off - 64 * (g * WBL + w);
+            VP[w] = z <= 0 ? ~(uint64_t)0 : z >= 64 ? 0 : (~(uint64_t)0) << z;
+            VN[w] = 0;
+        }
+        const int Lmax = wave_max_i32(L);
+        const int nchunk = (Lmax + K - 1) / K;
+        for (int ch = 0; ch < nchunk; ch++) {
+            if (ch * K < L) {
+                uint64_t *cp = CP + (int64_t)ch * CPW * 64;
+#pragma unroll
+                for (int w = 0; w < WBL; w++) { cp[w * 64] = VP[w]; cp[(WBL + w) * 64] = VN[w]; }
+#pragma unroll
+                for (int k = 0; k < NP; k++)
+#pragma unroll
+                    for (int w = 0; w < WBL; w++) cp[((2 + k) * WBL + w) * 64] = PL[k][w];
+            }
+            if (ch + 1 < nchunk) {
+#pragma unroll
+                for (int k = 0; k < K; k++) column(ch * K + k, k, false, ch * K + K);
+            }
+        }
+        int r = m - 1, cc = L - 1, ins = 0;
+        bool walking = valid;
+        for (int ch = nchunk - 1; ch >= 0; ch--) {
+            const int c0 = ch * K;
+            const bool act = walking && c0 < L;
+            if (!__any(act)) continue;
+            if (act) {
+                const uint64_t *cp = CP + (int64_t)ch * CPW * 64;
+#pragma unroll
+                for (int w = 0; w < WBL; w++) { VP[w] = cp[w * 64]; VN[w] = cp[(WBL + w) * 64]; }
+#pragma unroll
+                for (int k = 0; k < NP; k++)
+#pragma unroll
+                    for (int w = 0; w < WBL; w++) PL[k][w] = cp[((2 + k) * WBL + w) * 64];
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) column(c0 + k, k, true, c0 - K);
+            __syncthreads(); // one wavefront per workgroup: the group's LDS writes before the walk's reads
+            if (act) {
+                while (r >= 0 && cc >= c0) {
+                    const int b = r - cc + TOP - off;
+                    const int gw = b >> 6; // word of the window, over the group's lanes
+                    const ulonglong2 e = col[((cc - c0) * WBL + gw % WBL) * 64 + (lane - g + gw / WBL)];
+                    const uint64_t bit = ((uint64_t)1) << (b & 63);
+                    if (e.x & bit) { ins++; r--; }
+                    else if (e.y & bit) cc--;
+                    else { r--; cc--; }
+                }
+                if (r < 0) walking = false;
+            }
+            __syncthreads();
+        }
+        if (valid && g == 0) {
+            if (r >= 0) ins += r + 1;
             a.first_ins[p] = ins;
         }
     }
@@ -2060,7 +2292,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     } else {
         // Banded reverse pass, lane per location.  The locations are sorted by (band class, columns) so that the
-        // lanes of a wavefront run equally long; what no band class takes (2 x distance > 374) goes through the
+        // lanes of a wavefront run equally long; what no band class takes (distance > 59) goes through the
         // full-height kernels as dense per-size-class lists.
         const size_t NL = (size_t)st.total_loc;
         ULTRA_HIP_CHECK(ctx, st.startitems.ensure(NL * 4 * 4 + 64)); // keys in | keys out | locations in | locations out
@@ -2076,9 +2308,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         hipLaunchKernelGGL(k_start_keys, dim3((unsigned)((NL + 255) / 256)), dim3(256), 0, s, a, (int64_t)NL, k_in, v_in);
         {
             size_t tmp_bytes = 0;
-            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, NL, 0, kBandLBits + 3, s));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, NL, 0, kBandLBits + 4, s));
             ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
-            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, v_in, v_out, NL, 0, kBandLBits + 3, s));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, v_in, v_out, NL, 0, kBandLBits + 4, s));
         }
         hipLaunchKernelGGL(k_band_bounds, dim3(1), dim3(64), 0, s, k_out, (int64_t)NL, st.startinfo.as<int32_t>());
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
@@ -2122,15 +2354,13 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
                 switch (WB) {
                 case 1: hipLaunchKernelGGL((myers_bstart<1, 3>), grid, block, 0, cs, a, items, ni); break;
                 case 2: hipLaunchKernelGGL((myers_bstart<2, 3>), grid, block, 0, cs, a, items, ni); break;
-                case 4: hipLaunchKernelGGL((myers_bstart<4, 3>), grid, block, 0, cs, a, items, ni); break;
-                default: hipLaunchKernelGGL((myers_bstart<6, 3>), grid, block, 0, cs, a, items, ni); break;
+                default: break; // wider classes are not banded in the start pass (kStartBandClasses)
                 }
             } else {
                 switch (WB) {
                 case 1: hipLaunchKernelGGL((myers_bstart<1, 5>), grid, block, 0, cs, a, items, ni); break;
                 case 2: hipLaunchKernelGGL((myers_bstart<2, 5>), grid, block, 0, cs, a, items, ni); break;
-                case 4: hipLaunchKernelGGL((myers_bstart<4, 5>), grid, block, 0, cs, a, items, ni); break;
-                default: hipLaunchKernelGGL((myers_bstart<6, 5>), grid, block, 0, cs, a, items, ni); break;
+                default: break; // wider classes are not banded in the start pass (kStartBandClasses)
                 }
             }
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
@@ -2171,9 +2401,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in, st.bandinfo.as<int32_t>() + kBandBounds + kBandClasses);
         {
             size_t tmp_bytes = 0;
-            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 3, s));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 4, s));
             ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
-            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 3, s));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 4, s));
         }
         hipLaunchKernelGGL(k_band_bounds, dim3(1), dim3(64), 0, s, k_out, n_hits, st.bandinfo.as<int32_t>());
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
@@ -2199,8 +2429,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             units[c] = region[c] = 0;
             if (h_band[c] <= 0) continue;
             const int64_t chunks = ((int64_t)h_band[kBandClasses + 1 + c] + K - 1) / K;
-            region[c] = chunks * (2 + np) * band_rows(c); // 64-bit words per wavefront: 64 lanes x rows / 64 words each
-            const int64_t waves = ((int64_t)h_band[c] + 63) / 64;
+            region[c] = chunks * (2 + np) * band_rows(c) / band_group(c); // 64-bit words per wavefront: 64 lanes x (rows / 64 / lanes per hit) words each
+            const int per_wave = 64 / band_group(c); // hits per wavefront
+            const int64_t waves = ((int64_t)h_band[c] + per_wave - 1) / per_wave;
             int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * (c == 0 ? 20 : 10));
             u = std::min<int64_t>(u, std::max<int64_t>(1, (int64_t)((budget / kBandClasses) / (size_t)(region[c] * 8))));
             units[c] = u;
@@ -2227,22 +2458,39 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
             const int64_t ni = h_band[c];
             const int WB = band_words(c);
             const size_t band_lds = (size_t)band_chunk(c) * band_rows(c) * 16; // K columns x {Pv, Ph} of the window per lane
-            if (c == 0) {
+            if (c >= 3) {
+                const size_t glds = (size_t)8 * (c == 6 ? 3 : 2) * 64 * 16; // K columns x WBL words x 64 lanes x {Pv, Ph}
+                if (np == 3) {
+                    switch (c) {
+                    case 3: hipLaunchKernelGGL((myers_bandg<2, 2, 3>), grid, block, glds, cs, b, items, ni); break;
+                    case 4: hipLaunchKernelGGL((myers_bandg<3, 2, 3>), grid, block, glds, cs, b, items, ni); break;
+                    case 5: hipLaunchKernelGGL((myers_bandg<4, 2, 3>), grid, block, glds, cs, b, items, ni); break;
+                    case 6: hipLaunchKernelGGL((myers_bandg<4, 3, 3>), grid, block, glds, cs, b, items, ni); break;
+                    default: hipLaunchKernelGGL((myers_bandg<8, 2, 3>), grid, block, glds, cs, b, items, ni); break;
+                    }
+                } else {
+                    switch (c) {
+                    case 3: hipLaunchKernelGGL((myers_bandg<2, 2, 5>), grid, block, glds, cs, b, items, ni); break;
+                    case 4: hipLaunchKernelGGL((myers_bandg<3, 2, 5>), grid, block, glds, cs, b, items, ni); break;
+                    case 5: hipLaunchKernelGGL((myers_bandg<4, 2, 5>), grid, block, glds, cs, b, items, ni); break;
+                    case 6: hipLaunchKernelGGL((myers_bandg<4, 3, 5>), grid, block, glds, cs, b, items, ni); break;
+                    default: hipLaunchKernelGGL((myers_bandg<8, 2, 5>), grid, block, glds, cs, b, items, ni); break;
+                    }
+                }
+            } else if (c == 0) {
                 if (np == 3) hipLaunchKernelGGL((myers_band32<3>), grid, block, band_lds, cs, b, items, ni);
                 else hipLaunchKernelGGL((myers_band32<5>), grid, block, band_lds, cs, b, items, ni);
             } else if (np == 3) {
                 switch (WB) {
                 case 1: hipLaunchKernelGGL((myers_band<1, 3>), grid, block, band_lds, cs, b, items, ni); break;
                 case 2: hipLaunchKernelGGL((myers_band<2, 3>), grid, block, band_lds, cs, b, items, ni); break;
-                case 4: hipLaunchKernelGGL((myers_band<4, 3>), grid, block, band_lds, cs, b, items, ni); break;
-                default: hipLaunchKernelGGL((myers_band<6, 3>), grid, block, band_lds, cs, b, items, ni); break;
+                default: break; // 4 words and up: myers_bandg above
                 }
             } else {
                 switch (WB) {
                 case 1: hipLaunchKernelGGL((myers_band<1, 5>), grid, block, band_lds, cs, b, items, ni); break;
                 case 2: hipLaunchKernelGGL((myers_band<2, 5>), grid, block, band_lds, cs, b, items, ni); break;
-                case 4: hipLaunchKernelGGL((myers_band<4, 5>), grid, block, band_lds, cs, b, items, ni); break;
-                default: hipLaunchKernelGGL((myers_band<6, 5>), grid, block, band_lds, cs, b, items, ni); break;
+                default: break; // 4 words and up: myers_bandg above
                 }
             }
             ULTRA_HIP_CHECK(ctx, hipGetLastError());
@@ -2250,7 +2498,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         return ULTRA_OK;
         };
     }
-    // 3b: full-height kernels for what is left (distance > 374, or edit scripts wanted, or banding off).
+    // 3b: full-height kernels for what is left (distance > 1014, or edit scripts wanted, or banding off).
     //     Their own scratch buffer, split between the classes that have work; the launches overlap with
     //     each other and with the banded ones (these are bound by their critical path, not by the ALUs).
     const bool need_full = !use_band || h_band[kBandFallback] > 0;
