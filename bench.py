@@ -67,7 +67,7 @@ def parse_args():
     ap.add_argument("--world", default="c3", choices=["c3", "c2", "small"])
     ap.add_argument("--genes", type=int, default=0, help="override the annotation's gene count")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (0 = skip)")
-    ap.add_argument("--e2e-rounds", type=int, default=2, help="passes over the batches through ultra_pipe (0 = skip)")
+    ap.add_argument("--e2e-rounds", type=int, default=4, help="passes over the batches through ultra_pipe (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight in the end-to-end leg")
     ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
     ap.add_argument("--micro-scale", type=float, default=1.0, help="fraction of the micro-benchmarks' pair counts")
