@@ -172,39 +172,65 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
                 h = (h + 1) & a.ht_mask;
             }
         }
-        const int cnt = (int)((n1 - base) < 64 ? (n1 - base) : 64);
-        for (int j = 0; j < cnt; j++) {
-            const int32_t v = __shfl(val, j, 64), xj = __shfl(x, j, 64), yj = __shfl(y, j, 64), p0j = __shfl(p0, j, 64), p1j = __shfl(p1, j, 64);
-            if (v == -1) { plan_error(a, PERR_NO_PART, inst); continue; }
-            if (!(v & kFlankBit)) {
-                if ((int64_t)p1j <= fps) fps = p1j;
-                if ((int64_t)p0j >= lps) lps = p0j;
-                const int sb = a.part_off[v], se = a.part_off[v + 1];
-                for (int s0i = sb; s0i < se; s0i += 64) {
-                    const int si = s0i + lane;
-                    bool ov = false;
-                    int32_t sid = 0;
-                    if (si < se) {
-                        sid = a.part_seg[si];
-                        const SegRec r = a.seg[sid];
-                        ov = dev_overlaps(r.s0, r.s1, xj, yj);
-                    }
-                    const uint64_t m = __ballot(ov);
-                    const int pos = nh + __popcll(m & lt_mask);
-                    if (ov && pos < CAP) { keysA[pos] = ((uint64_t)(uint32_t)sid << 32) | (uint32_t)pos; A1[pos] = xj; A2[pos] = yj; }
-                    nh += __popcll(m);
-                }
-            } else {
-                const int f = v & ~kFlankBit;
-                int found = -1;
-                for (int t = 0; t < nf; t++) if (fl_id[t] == f) found = t;
-                __syncthreads();
-                if (found < 0) {
-                    if (nf < kMaxFlanks) { if (lane == 0) { fl_id[nf] = f; fl_x[nf] = xj; fl_y[nf] = yj; } nf++; }
-                    else too_big = true;
-                } else if (lane == 0) fl_y[found] = yj;
-                __syncthreads();
+        if (valid && val == -1) plan_error(a, PERR_NO_PART, inst);
+        const bool is_part = valid && val != -1 && !(val & kFlankBit);
+        const bool is_flank = valid && val != -1 && (val & kFlankBit);
+        // first / last part bounds (:221-226): a running minimum and maximum, whatever the order
+        {
+            int64_t mn = is_part ? (int64_t)p1 : (int64_t)1 << 40, mx = is_part ? (int64_t)p0 : -1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int64_t on = __shfl_xor(mn, o, 64), ox = __shfl_xor(mx, o, 64);
+                mn = on < mn ? on : mn; mx = ox > mx ? ox : mx;
             }
+            if (mn <= fps) fps = mn;
+            if (mx >= lps) lps = mx;
+        }
+        // flanks: first-seen list with the first NAM's start and the last NAM's end; few per chain, taken one by one
+        for (uint64_t fm = __ballot(is_flank); fm; fm &= fm - 1) {
+            const int j = __ffsll((long long)fm) - 1;
+            const int32_t v = __shfl(val, j, 64), xj = __shfl(x, j, 64), yj = __shfl(y, j, 64);
+            const int f = v & ~kFlankBit;
+            int found = -1;
+            for (int t = 0; t < nf; t++) if (fl_id[t] == f) found = t;
+            __syncthreads();
+            if (found < 0) {
+                if (nf < kMaxFlanks) { if (lane == 0) { fl_id[nf] = f; fl_x[nf] = xj; fl_y[nf] = yj; } nf++; }
+                else too_big = true;
+            } else if (lane == 0) fl_y[found] = yj;
+            __syncthreads();
+        }
+        // parts: the (NAM, segment of its part) pairs of these 64 NAMs are laid out one after the other and tested 64 at
+        // a time, one pair per lane - in (NAM, segment) order, so the position a hit is appended at is its arrival rank.
+        // (One NAM at a time, with the lanes over that part's handful of segments, cost three dependent loads per NAM.)
+        const int sb = is_part ? a.part_off[val] : 0;
+        const int len = is_part ? a.part_off[val + 1] - sb : 0;
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int P = incl - len, T = __shfl(incl, 63, 64);
+        for (int b0 = 0; b0 < T; b0 += 64) {
+            const int idx = b0 + lane;
+            int lo = 0, hi = 63; // largest lane j with P_j <= idx: the NAM this pair belongs to
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int mid = (lo + hi + 1) >> 1;
+                const int pm = __shfl(P, mid, 64);
+                if (pm <= idx) lo = mid; else hi = mid - 1;
+            }
+            const int sbj = __shfl(sb, lo, 64), pj = __shfl(P, lo, 64); // cross-lane reads stay outside the divergent part below
+            const int32_t xj = __shfl(x, lo, 64), yj = __shfl(y, lo, 64);
+            bool ov = false;
+            int32_t sid = 0;
+            if (idx < T) {
+                sid = a.part_seg[sbj + (idx - pj)];
+                const SegRec r = a.seg[sid];
+                ov = dev_overlaps(r.s0, r.s1, xj, yj);
+            }
+            const uint64_t m = __ballot(ov);
+            const int pos = nh + __popcll(m & lt_mask);
+            if (ov && pos < CAP) { keysA[pos] = ((uint64_t)(uint32_t)sid << 32) | (uint32_t)pos; A1[pos] = xj; A2[pos] = yj; }
+            nh += __popcll(m);
         }
     }
     if (nh > CAP) too_big = true;
@@ -463,7 +489,7 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
     }
     __syncthreads();
     if (!FILL) {
-        if (lane == 0) { a.n_cand[inst] = C; a.n_pair[inst] = npair; atomicMax(a.max_cand, C); }
+        if (lane == 0) { a.n_cand[inst] = C; a.n_pair[inst] = npair; if (C > *(volatile int32_t *)a.max_cand) atomicMax(a.max_cand, C); } // one address: an unconditional atomic per wavefront serialised the launch (3 ms)
         return;
     }
 
@@ -785,7 +811,7 @@ extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, cons
     a.overflow_list = m.p_over.as<int32_t>();
     int32_t *misc = m.p_misc.as<int32_t>(); // [0] overflow count, [1..2] error code / instance, [3] largest candidate count
     a.overflow_cnt = misc; a.err = misc + 1; a.max_cand = misc + 3;
-    constexpr int CAP_S = 256, CAP_L = 2048;
+    constexpr int CAP_S = 128, CAP_L = 2048; // 128 entries hold 99 % of the instances and let a CU keep twice the wavefronts in flight (the kernel is a chain of dependent loads)
     hipLaunchKernelGGL((k_plan<CAP_S, false>), dim3((unsigned)ni), dim3(64), plan_lds_bytes<CAP_S>(), s, a);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     uint32_t h_mask[8];
