@@ -72,6 +72,11 @@ struct ChainArgs {
     const int64_t *work_off;
     int32_t *status;
     int32_t skip_tiny;   // chain_quadratic: instances of at most kTiny MAMs were done by chain_tiny
+    // launch lists made on the device (k_chain_keys + sort): `list` is the whole sorted list and this launch takes the
+    // entries [seg_first[seg_lo], seg_first[seg_hi]); the grid only bounds their number from above
+    const int32_t *seg_first;
+    int32_t seg_lo, seg_hi;
+    int64_t work_stride; // n log n with device lists: bytes of tree arrays per list entry (work_off unused)
     // NAM (seed) chaining, SURVEY.md section 8 row f1: integer read-coverage objective of
     // colinear_solver.py:85-272; the whole DP vectors are the output (every co-optimal chain is wanted)
     int32_t nam;               // 0 = MAM objective, 1 = NAM objective
@@ -81,6 +86,25 @@ struct ChainArgs {
 };
 
 constexpr int kTiny = 48; // largest instance of the lane-per-instance kernel (chain_tiny)
+constexpr int kQuadSmall = 256;    // LDS entries per wave in the 4-waves-per-block launch
+
+// Launch lists by size on the device.  Segment of an instance: 0 .. kTiny = lane-per-instance kernel, largest first
+// (segment kTiny - n), then the small quadratic launch, the large one, the n log n solver.
+constexpr int kSegSmall = kTiny + 1, kSegBig = kTiny + 2, kSegTree = kTiny + 3, kSegEnd = kTiny + 4;
+__global__ void __launch_bounds__(256) k_chain_keys(const int32_t *cnt, int32_t n_inst, int32_t switch_n, uint32_t *keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inst) return;
+    const int n = cnt[i];
+    keys[i] = n > switch_n && n > 0 ? kSegTree : n <= kTiny ? (uint32_t)(kTiny - (n < 0 ? 0 : n)) : n <= kQuadSmall ? kSegSmall : kSegBig;
+}
+struct ListSlice { const int32_t *list; int n; };
+__device__ __forceinline__ ListSlice list_slice(const ChainArgs &a)
+{
+    if (!a.seg_first) return {a.list, a.nlist};
+    const int lo = a.seg_first[a.seg_lo];
+    return {a.list + lo, a.seg_first[a.seg_hi] - lo};
+}
 
 // ---- quadratic ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
@@ -88,8 +112,9 @@ __global__ void __launch_bounds__(256) chain_quadratic(ChainArgs a)
     extern __shared__ uint8_t lds_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int slot = blockIdx.x * wpb + wave;
-    if (slot >= a.nlist) return;
-    const int inst = a.list[slot];
+    const ListSlice ls = list_slice(a);
+    if (slot >= ls.n) return;
+    const int inst = ls.list[slot];
     const int64_t o = a.off[inst];
     const int n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
     const int cap = a.cap;
@@ -193,8 +218,9 @@ __global__ void __launch_bounds__(64) chain_tiny(ChainArgs a)
     const int slot = blockIdx.x * 64 + lane;
     int inst = 0, n = 0;
     int64_t o = 0;
-    if (slot < a.nlist) {
-        inst = a.list[slot];
+    const ListSlice ls = list_slice(a);
+    if (slot < ls.n) {
+        inst = ls.list[slot];
         o = a.off[inst];
         n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
         if (n > kTiny) {
@@ -268,8 +294,9 @@ template <bool NAM> __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs 
     extern __shared__ uint8_t lds_raw[];
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
-    if (slot >= a.nlist) return;
-    const int inst = a.list[slot];
+    const ListSlice ls = list_slice(a);
+    if (slot >= ls.n) return;
+    const int inst = ls.list[slot];
     const int64_t o = a.off[inst];
     const int n = a.cnt ? a.cnt[inst] : (int)(a.off[inst + 1] - o);
     if (n <= 0) {
@@ -295,7 +322,7 @@ template <bool NAM> __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs 
     double *cmC = (double *)(lds_raw + (size_t)nleaf * 16);
     int32_t *cmJ = (int32_t *)(lds_raw + (size_t)nleaf * 16 + (size_t)nchunk * 8);
     // global scratch of this instance
-    uint8_t *wk = a.work + a.work_off[slot];
+    uint8_t *wk = a.work + (a.work_off ? a.work_off[slot] : (int64_t)slot * a.work_stride);
     double *C = (double *)wk;                      // n+1
     int32_t *trace = (int32_t *)(wk + (size_t)(n + 1) * 8); // n+1
     int32_t *leaf_of = trace + (n + 1);            // n
@@ -461,7 +488,6 @@ template <bool NAM> __global__ void __launch_bounds__(64) chain_nlogn(ChainArgs 
     }
 }
 
-constexpr int kQuadSmall = 256;    // LDS entries per wave in the 4-waves-per-block launch
 constexpr int kLdsBudget = 160 * 1024;
 
 } // namespace
@@ -469,25 +495,114 @@ constexpr int kLdsBudget = 160 * 1024;
 void ultra_chain_free(ultra_ctx *ctx)
 {
     ChainState &ch = ctx->ch;
-    DevBuf *bufs[] = {&ch.ioff, &ch.off, &ch.x, &ch.y, &ch.c, &ch.d, &ch.val, &ch.idx, &ch.len, &ch.value, &ch.work, &ch.namC, &ch.namtrace, &ch.intron};
+    DevBuf *bufs[] = {&ch.ioff, &ch.off, &ch.x, &ch.y, &ch.c, &ch.d, &ch.val, &ch.idx, &ch.len, &ch.value, &ch.work, &ch.namC, &ch.namtrace, &ch.intron, &ch.sorttmp};
     for (DevBuf *b : bufs) b->release();
+}
+
+// MAM objective with the reference's solver switch, sizes known on the device only (d_cnt): the launch lists are made
+// there (segment of every instance, bucket sort) while h_bound - an upper bound of every instance's size - sizes
+// grids, LDS and the n log n solver's scratch.  Nothing is enqueued when kChainNeedExact comes back.
+static int chain_launch_device_lists(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_bound, const int64_t *d_off, const int32_t *d_cnt,
+                                     const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
+                                     int thr_s, int thr_l, int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out)
+{
+    const int sw = ctx->cfg.chain_switch_n;
+    int64_t ub_small = 0, ub_big = 0, ub_tree = 0;
+    int32_t max_big = 0, max_tree = 0;
+    for (int32_t i = 0; i < n_inst; i++) {
+        const int32_t n = h_bound[i];
+        if (n < 0) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: negative instance size");
+        if (n > sw && n > 0) { ub_tree++; max_tree = std::max(max_tree, n); }
+        if (n > kTiny) ub_small++;
+        if (n > kQuadSmall) { ub_big++; max_big = std::max(max_big, n); }
+    }
+    if (ub_tree > 0 && thr_l < 1) return kChainNeedExact;
+    if ((size_t)max_big * 20 > (size_t)kLdsBudget) return kChainNeedExact;
+    int tree_leaves = 1;
+    while (tree_leaves < max_tree + 1) tree_leaves <<= 1;
+    const size_t tree_lds = (size_t)tree_leaves * 16 + (size_t)((tree_leaves + 63) / 64) * 12 + 16;
+    if (ub_tree > 0 && tree_lds > (size_t)kLdsBudget) return kChainNeedExact;
+    const int64_t stride = ((((int64_t)max_tree + 1) * 12 + (int64_t)max_tree * 16) + 15) & ~(int64_t)15;
+    if (ub_tree * stride > ((int64_t)2 << 30)) return kChainNeedExact;
+
+    ChainState &ch = ctx->ch;
+    hipStream_t s = ctx->stream;
+    const size_t ni = (size_t)n_inst;
+    // ch.off: segment of every instance | instances grouped by segment | segment bounds (64) | status
+    ULTRA_HIP_CHECK(ctx, ch.off.ensure(ni * 8 + 64 * 4 + 64));
+    uint32_t *keys = ch.off.as<uint32_t>();
+    int32_t *i_out = (int32_t *)(keys + ni);
+    int32_t *d_first = i_out + ni, *d_status = d_first + 64;
+    if (d_status_out) *d_status_out = d_status;
+    if (ub_tree > 0) ULTRA_HIP_CHECK(ctx, ch.work.ensure((size_t)(ub_tree * stride) + 16));
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_status, 0, 4, s));
+    hipLaunchKernelGGL(k_chain_keys, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, d_cnt, n_inst, sw, keys);
+    ULTRA_HIP_CHECK(ctx, ultra_bucket_sort(s, keys, nullptr, n_inst, kSegEnd, i_out, d_first, 0, nullptr, ch.sorttmp));
+    ChainArgs a;
+    memset(&a, 0, sizeof a);
+    a.off = d_off; a.cnt = d_cnt; a.x = d_x; a.y = d_y; a.c = d_c; a.d = d_d;
+    a.val = d_val; a.idx = d_idx; a.len = d_len; a.value = d_value;
+    a.status = d_status; a.list = i_out; a.seg_first = d_first;
+    const int n_launch = 1 + (ub_small > 0) + (ub_big > 0) + (ub_tree > 0);
+    const bool spread = ctx->cfg.launch_lanes > 1 && n_launch > 1;
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    int li = 0;
+    auto next_lane = [&]() { return spread ? ctx->lane(li++) : s; };
+    if (ub_tree > 0) { // longest critical path first
+        hipStream_t cs = next_lane();
+        a.thr = thr_l; a.seg_lo = kSegTree; a.seg_hi = kSegEnd; a.cap = tree_leaves;
+        a.work = ch.work.as<uint8_t>(); a.work_off = nullptr; a.work_stride = stride;
+        if (tree_lds > 64 * 1024)
+            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_nlogn<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
+        hipLaunchKernelGGL(chain_nlogn<false>, dim3((unsigned)ub_tree), dim3(64), tree_lds, cs, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (ub_big > 0) {
+        hipStream_t cs = next_lane();
+        a.thr = thr_s; a.seg_lo = kSegBig; a.seg_hi = kSegTree; a.cap = max_big;
+        const size_t shmem = (size_t)max_big * 20;
+        if (shmem > 64 * 1024)
+            ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)chain_quadratic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(chain_quadratic, dim3((unsigned)ub_big), dim3(64), shmem, cs, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (ub_small > 0) {
+        hipStream_t cs = next_lane();
+        a.thr = thr_s; a.seg_lo = kSegSmall; a.seg_hi = kSegBig; a.cap = kQuadSmall;
+        hipLaunchKernelGGL(chain_quadratic, dim3((unsigned)((ub_small + 3) / 4)), dim3(256), (size_t)4 * kQuadSmall * 20, cs, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    {
+        hipStream_t cs = next_lane();
+        a.thr = thr_s; a.seg_lo = 0; a.seg_hi = kSegSmall; a.cap = 0;
+        hipLaunchKernelGGL(chain_tiny, dim3((unsigned)((ni + 63) / 64)), dim3(64), 0, cs, a);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    return ULTRA_OK;
 }
 
 // Launches the chaining kernels for n_inst instances whose MAM arrays are already in device memory.
 // h_cnt: per-instance MAM counts on the host (used to pick solver / LDS sizes); d_cnt: the same on
 // the device, or nullptr when the counts are d_off[i+1] - d_off[i].  Asynchronous on ctx->stream;
 // *d_status (device int, zeroed here) is non-zero afterwards if an instance hit the reference's
-// "BUG" state.
+// "BUG" state.  cnt_is_bound (MAM objective, d_cnt given): h_cnt only bounds the sizes from above and the launch
+// lists are made on the device (chain_launch_device_lists); kChainNeedExact = a limit failed on the bounds, nothing
+// was enqueued, call again with the exact counts.
 int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, const int64_t *d_off, const int32_t *d_cnt,
                        const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
                        int32_t solver, int32_t overlap_small, int32_t overlap_large,
                        int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out, const ultra_nam_chain *nam,
-                       const ultra_chain_ws *ws)
+                       const ultra_chain_ws *ws, bool cnt_is_bound)
 {
     const size_t qstride = nam ? 24 : 20; // LDS bytes per entry of the quadratic kernel
     if (solver < 0 || solver > 2) return ultra_fail(ctx, ULTRA_E_ARG, "chaining: solver must be 0, 1 or 2");
     const int thr_s = overlap_small < 0 ? ctx->cfg.overlap_small : overlap_small;
     const int thr_l = overlap_large < 0 ? ctx->cfg.overlap_large : overlap_large;
+    if (cnt_is_bound) {
+        if (solver != 0 || nam || !d_cnt || ws) return kChainNeedExact;
+        return chain_launch_device_lists(ctx, n_inst, h_cnt, d_off, d_cnt, d_x, d_y, d_c, d_d, d_val, thr_s, thr_l, d_idx, d_len, d_value, d_status_out);
+    }
     std::vector<int32_t> small, big, tree;
     std::vector<int32_t> tiny_n[kTiny + 1]; // MAM instances of at most kTiny entries, by size
     size_t n_tiny = 0;

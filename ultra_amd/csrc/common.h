@@ -81,11 +81,12 @@ struct MyersState {
     uint8_t h_lut[256] = {};
     bool h_seen[256] = {};
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool times_pending = false;  // the last run returned before its final synchronisation (ultra_myers_run_impl, defer_sync)
 };
 
 struct ChainState {
     uint8_t *fixed = nullptr;        // device address of chain.hip's fixed scratch array on this context's GPU
-    DevBuf ioff, off, x, y, c, d, val, idx, len, value, work, namC, namtrace, intron;
+    DevBuf ioff, off, x, y, c, d, val, idx, len, value, work, namC, namtrace, intron, sorttmp;
     std::vector<int32_t> h_list;     // kept alive until the stream has consumed them
     std::vector<int64_t> h_workoff;
 };
@@ -134,9 +135,9 @@ struct ultra_ctx {
     hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {};
     // lane i of a forked section: the auxiliary streams in use, then the main stream itself
     hipStream_t lane(int i) const { i %= cfg.launch_lanes; return i < cfg.launch_lanes - 1 ? aux[i] : stream; }
-    // enqueued on `stream` by the Myers run right after the start pass has been launched: work of the caller that
-    // only needs the forward results rides under the remaining passes and shares their next host synchronisation
-    std::function<int()> mid_hook;
+    // enqueued by the Myers run on the stream it names, right after the start pass has been launched: work of the caller
+    // that only needs the forward results rides under the remaining passes and shares their next host synchronisation
+    std::function<int(hipStream_t)> mid_hook;
     ultra_cfg cfg;
     std::string err;
     hipDeviceProp_t prop;
@@ -212,7 +213,8 @@ void ultra_launch_presence(hipStream_t s, const uint8_t *raw, int64_t n, uint32_
 void ultra_launch_encode(hipStream_t s, const uint8_t *raw, int64_t n, const uint8_t *lut, uint8_t *seq, uint8_t *rseq, int64_t at, int64_t N);
 void ultra_mam_remap_pairs(ultra_ctx *ctx, int32_t n_cand);
 int ultra_myers_host_perm(ultra_ctx *ctx);
-int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops);
+int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync = false);
+int ultra_myers_collect_times(ultra_ctx *ctx);
 // caller-provided device workspace of ultra_chain_launch (instead of the context's growable buffers)
 struct ultra_chain_ws {
     uint8_t *aux; size_t aux_cap;   // work offsets | launch list | status word: ultra_chain_aux_bytes(n_inst)
@@ -223,10 +225,14 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
                        const int32_t *d_x, const int32_t *d_y, const int32_t *d_c, const int32_t *d_d, const double *d_val,
                        int32_t solver, int32_t overlap_small, int32_t overlap_large,
                        int32_t *d_idx, int32_t *d_len, double *d_value, int32_t **d_status_out,
-                       const ultra_nam_chain *nam = nullptr, const ultra_chain_ws *ws = nullptr);
+                       const ultra_nam_chain *nam = nullptr, const ultra_chain_ws *ws = nullptr, bool cnt_is_bound = false);
+constexpr int kChainNeedExact = -1000; // ultra_chain_launch with cnt_is_bound: a limit failed on the bounds, nothing was enqueued
 int ultra_chain_scratch_init(ultra_ctx *ctx);
-// exclusive scan of n 64-bit values on ctx->stream (tmp: scratch, grown as needed)
-hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp);
+// exclusive scan of n 64-bit values on `on` (ctx->stream when null); tmp: scratch, grown as needed
+hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp, hipStream_t on = nullptr);
+// ids (or vals) grouped by a small key: three launches on s (myers.hip)
+hipError_t ultra_bucket_sort(hipStream_t s, const uint32_t *keys, const int32_t *vals, int64_t n, int nb, int32_t *out,
+                             int32_t *first, int stride, int32_t *gfirst, DevBuf &tmp);
 void ultra_myers_free(ultra_ctx *ctx);
 void ultra_chain_free(ultra_ctx *ctx);
 void ultra_mam_free(ultra_ctx *ctx);

@@ -481,12 +481,12 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     // ---- slot layout: one slot per location of a candidate's pair (+1 for its contained-read pair).  It only needs
     //      the forward pass, so it is enqueued from inside the Myers run (behind the start pass) and its total
     //      comes back with that run's next host synchronisation. ----
-    ctx->mid_hook = [ctx, &m, &my, nc, ni, s]() -> int {
+    ctx->mid_hook = [ctx, &m, &my, nc, ni](hipStream_t s) -> int {
         if (ni == 0) return ULTRA_OK;
         if (nc > 0) {
             hipLaunchKernelGGL(k_cand_cap, dim3((nc + 255) / 256), dim3(256), 0, s, m.pair.as<int32_t>(), m.pairc.as<int32_t>(),
                                my.nloc.as<int32_t>(), m.cap.as<uint64_t>(), nc);
-            ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, m.cap.as<uint64_t>(), m.capoff.as<uint64_t>(), nc, m.scantmp));
+            ULTRA_HIP_CHECK(ctx, ultra_scan_u64(ctx, m.cap.as<uint64_t>(), m.capoff.as<uint64_t>(), nc, m.scantmp, s));
             hipLaunchKernelGGL(k_scan_close, dim3(1), dim3(64), 0, s, m.cap.as<uint64_t>(), m.capoff.as<uint64_t>(), (int64_t)nc);
             hipLaunchKernelGGL(k_gather_i64, dim3((ni + 1 + 255) / 256), dim3(256), 0, s, m.capoff.as<int64_t>(), m.candoff.as<int64_t>(),
                                m.instbase.as<int64_t>(), ni + 1);
@@ -498,12 +498,18 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
         }
         return ULTRA_OK;
     };
-    int rc = ultra_myers_run_impl(ctx, false);
+    int rc = ultra_myers_run_impl(ctx, false, true); // returns with the traceback in flight: k_mam_build queues behind it
     ctx->mid_hook = nullptr;
     if (rc != ULTRA_OK) return rc;
-    if (ni == 0) { m.ran = true; return ULTRA_OK; }
-    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ultra_drain_guard drain(ctx);
+    if (ni == 0) {
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        if (my.times_pending) { const int trc = ultra_myers_collect_times(ctx); if (trc != ULTRA_OK) return trc; }
+        drain.dismiss();
+        m.ran = true;
+        return ULTRA_OK;
+    }
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[0], s));
     m.total_cap = m.pinned_base[ni];
     const size_t T = (size_t)std::max<int64_t>(m.total_cap, 1);
@@ -542,26 +548,28 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[1], s));
     // ---- chaining (solver switch of classify_read_with_mams.py:560-575) ----
-    // The host sorts the instances into launches by size.  An instance cannot hold more MAMs than it has slots, and
-    // the slot counts are on the host already: when none of them passes the solver switch every instance takes the
-    // quadratic solver whatever its exact size, and the launch needs no read-back of the MAM counts in between.
+    // The host sorts the instances into launches by size while k_mam_build runs.  An instance cannot hold more MAMs
+    // than it has slots, and the slot counts are on the host already: the launches are made up from these bounds, an
+    // instance whose bound passes the solver switch is listed for both solvers and the kernels pick it up by its
+    // actual count on the device.  Only when a limit fails on the bounds are the exact counts read back first.
     m.h_nmam.resize((size_t)ni);
     m.h_slots.resize((size_t)ni);
+    for (int32_t i = 0; i < ni; i++) m.h_slots[(size_t)i] = (int32_t)(m.pinned_base[i + 1] - m.pinned_base[i]);
     bool exact_needed = false;
-    for (int32_t i = 0; i < ni; i++) {
-        const int64_t slots = m.pinned_base[i + 1] - m.pinned_base[i];
-        m.h_slots[(size_t)i] = (int32_t)slots;
-        if (slots > ctx->cfg.chain_switch_n) exact_needed = true;
-    }
-    if (exact_needed) {
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
-        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[2], s));
     int32_t *d_status = nullptr;
-    rc = ultra_chain_launch(ctx, ni, exact_needed ? m.h_nmam.data() : m.h_slots.data(), m.instbase.as<int64_t>(), m.nmam.as<int32_t>(),
+    rc = ultra_chain_launch(ctx, ni, m.h_slots.data(), m.instbase.as<int64_t>(), m.nmam.as<int32_t>(),
                             a.mx, a.my, a.mc, a.md, a.mval,
-                            0, -1, -1, m.chainidx.as<int32_t>(), m.chainlen.as<int32_t>(), m.value.as<double>(), &d_status);
+                            0, -1, -1, m.chainidx.as<int32_t>(), m.chainlen.as<int32_t>(), m.value.as<double>(), &d_status, nullptr, nullptr, true);
+    if (rc == kChainNeedExact) {
+        exact_needed = true;
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[2], s));
+        rc = ultra_chain_launch(ctx, ni, m.h_nmam.data(), m.instbase.as<int64_t>(), m.nmam.as<int32_t>(),
+                                a.mx, a.my, a.mc, a.md, a.mval,
+                                0, -1, -1, m.chainidx.as<int32_t>(), m.chainlen.as<int32_t>(), m.value.as<double>(), &d_status);
+    }
     if (rc != ULTRA_OK) { (void)hipStreamSynchronize(s); return rc; }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[3], s));
     // ---- compact the chains for the fetch ----
@@ -584,6 +592,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
     if (!exact_needed) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (my.times_pending) { const int trc = ultra_myers_collect_times(ctx); if (trc != ULTRA_OK) return trc; }
     for (int32_t i = 0; i < ni; i++) m.total_mam += m.h_nmam[(size_t)i];
     if (status != 0)
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_run: an instance reached the reference's 'BUG' state in the n log n chainer");

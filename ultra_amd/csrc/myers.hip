@@ -1829,8 +1829,9 @@ int class_of(int m)
 
 } // namespace
 
-hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp)
+hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int64_t n, DevBuf &tmp, hipStream_t on)
 {
+    const hipStream_t ss = on ? on : ctx->stream;
     // three-level exclusive scan (n <= 2^30)
     if (n <= 0) return hipSuccess;
     int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -1838,18 +1839,108 @@ hipError_t ultra_scan_u64(ultra_ctx *ctx, const uint64_t *in, uint64_t *out, int
     if ((e = tmp.ensure(sizeof(uint64_t) * (size_t)(2 * nb + 2 * SCAN_BLOCK + 2 * ((nb + SCAN_BLOCK - 1) / SCAN_BLOCK)))) != hipSuccess) return e;
     uint64_t *bs = tmp.as<uint64_t>();
     uint64_t *bs2 = bs + nb;
-    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, in, out, bs, n);
+    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ss, in, out, bs, n);
     if (nb > 1) {
         if (nb > (int64_t)SCAN_BLOCK * SCAN_BLOCK) return hipErrorInvalidValue;
         int64_t nb2 = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
         uint64_t *bs3 = bs2 + nb;
-        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ctx->stream, bs, bs2, bs3, nb);
+        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ss, bs, bs2, bs3, nb);
         if (nb2 > 1) {
-            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, bs3, bs3 + nb2, (uint64_t *)nullptr, nb2);
-            hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ctx->stream, bs2, bs3 + nb2, nb);
+            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_BLOCK), 0, ss, bs3, bs3 + nb2, (uint64_t *)nullptr, nb2);
+            hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb2), dim3(SCAN_BLOCK), 0, ss, bs2, bs3 + nb2, nb);
         }
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, out, bs2, n);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ss, out, bs2, n);
     }
+    return hipGetLastError();
+}
+
+// ---- bucket sort: ids grouped by a small key --------------------------------------------------------------------
+// Three launches (histogram, scan of the buckets, scatter) instead of a radix sort's dozen: the keys have a few
+// thousand values at most, a block counts its 16384 elements in LDS and reserves its share of every bucket with one
+// global atomic.  The order inside a bucket is arbitrary (it differs from run to run); callers only rely on the grouping.
+namespace {
+constexpr int kBsThreads = 1024, kBsPer = 16;
+__global__ void __launch_bounds__(kBsThreads) k_bsort_hist(const uint32_t *keys, int64_t n, int nb, int32_t *hist)
+{
+    extern __shared__ int32_t lh[];
+    for (int b = threadIdx.x; b < nb; b += kBsThreads) lh[b] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kBsThreads * kBsPer;
+#pragma unroll
+    for (int k = 0; k < kBsPer; k++) {
+        const int64_t i = base + (int64_t)k * kBsThreads + threadIdx.x;
+        if (i < n) atomicAdd(&lh[keys[i]], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += kBsThreads) { const int32_t c = lh[b]; if (c) atomicAdd(&hist[b], c); }
+}
+// one block: first[b] = cursor[b] = elements in the buckets before b (b = 0 .. nb); gfirst[g] = first[g * stride]
+__global__ void __launch_bounds__(kBsThreads) k_bsort_scan(const int32_t *hist, int nb, int32_t *first, int32_t *cursor, int stride, int32_t *gfirst)
+{
+    __shared__ int32_t part[kBsThreads];
+    const int per = (nb + kBsThreads - 1) / kBsThreads;
+    const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    int32_t sum = 0;
+    for (int b = lo; b < hi; b++) sum += hist[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < kBsThreads; d <<= 1) {
+        const int32_t t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int32_t run = part[threadIdx.x] - sum;
+    for (int b = lo; b < hi; b++) {
+        first[b] = run; cursor[b] = run;
+        if (gfirst && b % stride == 0) gfirst[b / stride] = run;
+        run += hist[b];
+    }
+    if (threadIdx.x == kBsThreads - 1) {
+        first[nb] = part[threadIdx.x];
+        if (gfirst && nb % stride == 0) gfirst[nb / stride] = part[threadIdx.x];
+    }
+}
+__global__ void __launch_bounds__(kBsThreads) k_bsort_scatter(const uint32_t *keys, const int32_t *vals, int64_t n, int nb, int32_t *cursor, int32_t *out)
+{
+    extern __shared__ int32_t lh[];
+    for (int b = threadIdx.x; b < nb; b += kBsThreads) lh[b] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kBsThreads * kBsPer;
+    uint32_t key[kBsPer];
+    int32_t rank[kBsPer];
+#pragma unroll
+    for (int k = 0; k < kBsPer; k++) {
+        const int64_t i = base + (int64_t)k * kBsThreads + threadIdx.x;
+        key[k] = 0; rank[k] = 0;
+        if (i < n) { key[k] = keys[i]; rank[k] = atomicAdd(&lh[key[k]], 1); }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += kBsThreads) { const int32_t c = lh[b]; lh[b] = c ? atomicAdd(&cursor[b], c) : 0; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBsPer; k++) {
+        const int64_t i = base + (int64_t)k * kBsThreads + threadIdx.x;
+        if (i < n) out[lh[key[k]] + rank[k]] = vals ? vals[i] : (int32_t)i;
+    }
+}
+} // namespace
+
+// out = vals (or 0 .. n-1) grouped by keys[i] < nb, ascending; first (nb + 1 entries, device) = first position of every
+// bucket; gfirst (optional, nb / stride + 1 entries) = the same for every stride-th bucket.  n < 2^31, nb <= 8192.
+hipError_t ultra_bucket_sort(hipStream_t s, const uint32_t *keys, const int32_t *vals, int64_t n, int nb, int32_t *out,
+                             int32_t *first, int stride, int32_t *gfirst, DevBuf &tmp)
+{
+    if (nb <= 0 || nb > 8192 || n < 0 || n > 0x7fffffff) return hipErrorInvalidValue;
+    hipError_t e;
+    if ((e = tmp.ensure((size_t)nb * 8 + 64)) != hipSuccess) return e;
+    int32_t *hist = tmp.as<int32_t>(), *cursor = hist + nb;
+    if ((e = hipMemsetAsync(hist, 0, (size_t)nb * 4, s)) != hipSuccess) return e;
+    const unsigned blocks = (unsigned)((n + kBsThreads * kBsPer - 1) / (kBsThreads * kBsPer));
+    const size_t lds = (size_t)nb * 4;
+    if (blocks) hipLaunchKernelGGL(k_bsort_hist, dim3(blocks), dim3(kBsThreads), lds, s, keys, n, nb, hist);
+    hipLaunchKernelGGL(k_bsort_scan, dim3(1), dim3(kBsThreads), 0, s, hist, nb, first, cursor, stride > 0 ? stride : 1, gfirst);
+    if (blocks) hipLaunchKernelGGL(k_bsort_scatter, dim3(blocks), dim3(kBsThreads), lds, s, keys, vals, n, nb, cursor, out);
     return hipGetLastError();
 }
 
@@ -2170,7 +2261,24 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
     return ultra_myers_stage_pairs(ctx, n_pairs);
 }
 
-int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
+// The per-pass times of the last run (events of the run's streams; the caller has synchronised).
+int ultra_myers_collect_times(ultra_ctx *ctx)
+{
+    MyersState &st = ctx->my;
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[0], st.ev[0], st.ev[1]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[1], st.ev[1], st.ev[2]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[2], st.ev[2], st.ev[3]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[3], st.ev[0], st.ev[3]));
+    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[4], st.ev[0], st.ev[4]));
+    for (auto &bk : st.buckets) { bk.fwd_ms = 0; if (bk.n_fwd > 0) ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&bk.fwd_ms, bk.ev0, bk.ev1)); }
+    st.times_pending = false;
+    return ULTRA_OK;
+}
+
+// defer_sync: return with the traceback still in flight on ctx->stream when everything the caller needs on the host
+// has arrived (st.times_pending tells); the caller enqueues its next kernels behind it, synchronises once at the end
+// and calls ultra_myers_collect_times.
+int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
 {
     MyersState &st = ctx->my;
     if (!st.staged) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_myers_run: no staged batch");
@@ -2178,11 +2286,12 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     hipStream_t s = ctx->stream;
     const int32_t n = st.n_pairs;
     st.ran = false;
+    st.times_pending = false;
     st.total_loc = st.total_hit = 0;
     for (auto &m : st.ms) m = 0;
     if (n == 0) {
         if (ctx->mid_hook) {
-            const int hrc = ctx->mid_hook();
+            const int hrc = ctx->mid_hook(s);
             if (hrc != ULTRA_OK) return hrc;
             ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         }
@@ -2368,7 +2477,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
-    if (ctx->mid_hook) { const int hrc = ctx->mid_hook(); if (hrc != ULTRA_OK) return hrc; }
+    if (ctx->mid_hook) { const int hrc = ctx->mid_hook(s); if (hrc != ULTRA_OK) return hrc; }
     // ---- pass 3: first-location traceback ----
     a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
     a.ops_off = want_ops ? st.opsoff.as<int64_t>() : nullptr;
@@ -2380,6 +2489,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0 && st.S + 1 <= 32;
     a.nw_items = nullptr;
     bool forked = false;
+    bool hook_arrived = false; // a host synchronisation has followed the caller's mid-run work on s
     int32_t full_first[kNumSizeClasses + 1], full_edmax[kNumSizeClasses];
     for (auto &v : full_first) v = 0;
     for (auto &v : full_edmax) v = 0;
@@ -2410,6 +2520,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
         int32_t h_info[kBandBounds + kBandClasses + kNumSizeClasses];
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, sizeof h_info, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        hook_arrived = true;
         int32_t band_first[kBandClasses + 1];
         for (int c = 0; c <= kBandClasses; c++) band_first[c] = h_info[c];
         for (int c = 0; c < kBandClasses; c++) {
@@ -2569,13 +2680,17 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops)
     }
     if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[3], s));
+    if (defer_sync && hook_arrived) {
+        st.times_pending = true;
+        drain.dismiss();
+        st.ran = true;
+        return ULTRA_OK;
+    }
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[0], st.ev[0], st.ev[1]));
-    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[1], st.ev[1], st.ev[2]));
-    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[2], st.ev[2], st.ev[3]));
-    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[3], st.ev[0], st.ev[3]));
-    ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&st.ms[4], st.ev[0], st.ev[4]));
-    for (auto &bk : st.buckets) { bk.fwd_ms = 0; if (bk.n_fwd > 0) ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&bk.fwd_ms, bk.ev0, bk.ev1)); }
+    {
+        const int trc = ultra_myers_collect_times(ctx);
+        if (trc != ULTRA_OK) return trc;
+    }
     drain.dismiss();
     st.ran = true;
     return ULTRA_OK;
