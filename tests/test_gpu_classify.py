@@ -121,6 +121,49 @@ def test_low_complexity_reads_many_locations(ctx):
         assert _same(classify_port.classify(sol, *idx, read, None, 0.6), g)
 
 
+def test_solver_switch_is_taken_on_the_device(monkeypatch):
+    """The chaining launches are made up from slot bounds on the host and the actual MAM counts on the device
+    (classify_read_with_mams.py:560-575: more than 200 MAMs -> n log n solver).  With the switch lowered to 6 on both
+    sides, instances land on either side of it with bounds above it; a threshold the n log n solver cannot take makes
+    the library read the exact counts back and fail exactly when such an instance exists."""
+    from array import array
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage, lib
+    from ultra_amd.synth import Mem, key_of
+    rng = np.random.RandomState(11)
+    insts, seg, flank, p2s, s2g, g2s = [], {}, {}, {}, {}, {"g": array('L')}
+    pos, segs = 1000, []
+    for i in range(30):
+        ln = int(rng.choice([6, 8, 12, 20, 40, 90]))
+        s = helpers.rand_seq(rng, ln, "AC" if i % 2 else "ACGT")
+        k = key_of(1, pos, pos + ln)
+        seg[k] = s; s2g[k] = {"g"}; p2s[k] = array('L', [1, pos, pos + ln]); g2s["g"].extend([1, pos, pos + ln])
+        segs.append((pos, pos + ln, s))
+        pos += ln + 300
+    for r in range(60):
+        read = helpers.rand_seq(rng, int(rng.randint(60, 400)), "AC" if r % 3 else "ACGT")
+        a, b, s = segs[int(rng.randint(0, len(segs)))]
+        insts.append((read, [Mem(a, b - 1, 0, b - a - 1, b - a, 0, "1^%d^%d" % (a, b))]))
+    idx = (seg, flank, p2s, s2g, g2s)
+    monkeypatch.setattr(classify_port, "SWITCH_N", 6)
+    want = [classify_port.classify(sol, *idx, read, None, 0.6) for read, sol in insts]
+    sizes = [len(w[2]) for w in want]
+    assert min(sizes) <= 6 < max(sizes)          # both solvers are taken
+    c = lib.Context(0, cfg={"chain_switch_n": 6})
+    try:
+        got = stage.main_batch([(sol, read) for read, sol in insts], *idx, min_acc=0.6, ctx=c)
+    finally:
+        c.close()
+    for w, g in zip(want, got):
+        assert _same(w, g)
+    c = lib.Context(0, cfg={"chain_switch_n": 6, "overlap_large": 0})
+    try:
+        with pytest.raises(lib.UltraError, match="overlap threshold"):
+            stage.main_batch([(sol, read) for read, sol in insts], *idx, min_acc=0.6, ctx=c)
+    finally:
+        c.close()
+
+
 def test_many_candidates_per_instance(ctx):
     """A gene of 1 300 short segments: every instance has more candidates than the two-instances-per-wavefront form
     of the MAM kernel keeps in LDS, so the batch takes the wavefront-per-instance form (several candidates per lane)."""
