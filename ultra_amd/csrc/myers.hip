@@ -1571,13 +1571,13 @@ __global__ void __launch_bounds__(64) myers_bstart(MyArgs a, const int32_t *item
 
 // Sort key of every location for the start pass: band class by 2 x distance, then the number of columns, longest
 // first; locations beyond every band class are keyed by the size class of their query (dense lists for
-// myers_mega<MODE_REV>).  Same layout as k_band_keys, so k_band_bounds serves both.
+// myers_mega<MODE_REV>).
 __global__ void __launch_bounds__(256) k_start_keys(MyArgs a, int64_t n_loc, uint32_t *keys, int32_t *idx);
 
-// Sort key of every hit: band class by its distance (band rows needed: 2*ed + 3), then the length
-// of its first location, longest first - the lanes of a wavefront then run equally long.  Hits beyond
-// every band class are keyed by the size class of their query instead: each full-height kernel then
-// gets a dense list of exactly its hits.
+// Every hit is routed by its distance (band rows needed: 2*ed + 3) and, inside its band class, sorted by the length
+// of its first location, longest first - the lanes of a wavefront then run equally long.  Hits beyond every band
+// class are keyed by the size class of their query instead: each full-height kernel then gets a dense list of
+// exactly its hits.  (kBandLBits / kFullLBits: key layout of the banded start pass, k_start_keys.)
 constexpr uint32_t kBandLBits = 24, kFullLBits = 20;
 constexpr int kNumSizeClasses = 14;
 constexpr int kBandBounds = kBandClasses + kNumSizeClasses + 1; // first sorted position of each group, then the end
@@ -1586,25 +1586,70 @@ __device__ __forceinline__ uint32_t size_class_of(int m)
     return m <= 256 ? (uint32_t)((m - 1) >> 6) : m <= 384 ? 4u : m <= 512 ? 5u : m <= 768 ? 6u : m <= 1024 ? 7u : m <= 1536 ? 8u
          : m <= 2048 ? 9u : m <= 4096 ? 10u : m <= 8192 ? 11u : m <= 16384 ? 12u : 13u;
 }
-// edmax[size class] = largest distance among the hits no band class takes (sizes the stored band of the lane-group kernels)
-__global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys, int32_t *edmax)
+// Traceback routing keys, 14 bits (two radix passes instead of the four a 28-bit key with the exact length took):
+// band class (by distance), then a bin of the first location's length, longest first - exact below 256 columns,
+// 32 bins per octave above (the lanes of a wavefront then differ by 3 % at most).  Hits beyond every band class:
+// size class of the query, then 32 coarse bins.
+constexpr int kTbBins = 1024, kTbFullBins = 32, kTbKeyBits = 14;
+static_assert(kBandClasses * kTbBins + kNumSizeClasses * kTbFullBins <= (1 << kTbKeyBits), "routing key bits");
+__device__ __forceinline__ uint32_t tb_length_bin(uint32_t L) // 0 .. 767
 {
+    if (L < 256) return L;
+    const int e = 31 - __builtin_clz(L); // 8 .. 23 (a location is shorter than 2^24 columns)
+    const uint32_t b = 256u + (uint32_t)(e - 8) * 32u + ((L >> (e - 5)) & 31u);
+    return b < 767u ? b : 767u;
+}
+// info[kBandBounds + c] = longest first location of band class c; info[kBandBounds + kBandClasses + size class] =
+// largest distance among the hits no band class takes (sizes the stored band of the lane-group kernels)
+__global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys, int32_t *info)
+{
+    // the maxima go through LDS: the hits come in the order of the sorted pairs, lengths growing, and a maximum kept
+    // with one global atomic per hit would take one almost every time
+    __shared__ int32_t top[kBandClasses + kNumSizeClasses];
+    if (threadIdx.x < kBandClasses + kNumSizeClasses) top[threadIdx.x] = 0;
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_hits) return;
-    const int32_t p = a.hit_pairs[i];
-    const int ed = a.ed[p];
-    const int64_t lo = a.loc_off[p];
-    const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
-    // ed + 1 diagonals, one spare on either side, up to 7 lost to the window's 8-row alignment: ed <= 64 WB - 10
-    uint32_t c = 0;
-    while (c < kBandFallback && ed > band_rows((int)c) - 10) c++;
-    if (c < kBandFallback) keys[i] = (c << kBandLBits) | (((1u << kBandLBits) - 1u) - (L < (1u << kBandLBits) ? L : (1u << kBandLBits) - 1u));
-    else {
-        const uint32_t sc = size_class_of(a.q_len[p]);
-        keys[i] = (c << kBandLBits) | (sc << kFullLBits) | (((1u << kFullLBits) - 1u) - (L < (1u << kFullLBits) ? L : (1u << kFullLBits) - 1u));
-        atomicMax(&edmax[sc], ed);
+    if (i < n_hits) {
+        const int32_t p = a.hit_pairs[i];
+        const int ed = a.ed[p];
+        const int64_t lo = a.loc_off[p];
+        const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
+        // ed + 1 diagonals, one spare on either side, up to 7 lost to the window's 8-row alignment: ed <= 64 WB - 10
+        uint32_t c = 0;
+        while (c < kBandFallback && ed > band_rows((int)c) - 10) c++;
+        int slot, v;
+        if (c < kBandFallback) {
+            keys[i] = c * kTbBins + (kTbBins - 1 - tb_length_bin(L));
+            slot = (int)c; v = (int)L;
+        } else {
+            const uint32_t sc = size_class_of(a.q_len[p]);
+            keys[i] = kBandClasses * kTbBins + sc * kTbFullBins + (kTbFullBins - 1 - (tb_length_bin(L) >> 5));
+            slot = kBandClasses + (int)sc; v = ed;
+        }
+        if (v > top[slot]) atomicMax(&top[slot], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBandClasses + kNumSizeClasses) {
+        const int32_t v = top[threadIdx.x];
+        int32_t *g = info + kBandBounds + threadIdx.x;
+        if (v > *(volatile int32_t *)g) atomicMax(g, v);
     }
 }
+// info[g] = first sorted position of group g (the band classes, then the size classes of the rest, then the end)
+__global__ void k_band_groups(const uint32_t *keys, int64_t n, int32_t *info)
+{
+    const int g = threadIdx.x;
+    if (g >= kBandBounds) return;
+    const uint32_t thr = g < kBandClasses ? (uint32_t)g * kTbBins : kBandClasses * kTbBins + (uint32_t)(g - kBandClasses) * kTbFullBins;
+    int64_t lo = 0, hi = n;
+    if (g == kBandBounds - 1) lo = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < thr) lo = mid + 1; else hi = mid;
+    }
+    info[g] = (int32_t)lo;
+}
+// keys of the banded start pass (k_start_keys below):
 // info[g] = first sorted position of group g (the band classes, then the 14 size classes of the
 // rest, then the end); info[kBandBounds + c] = longest first location of band class c
 __global__ void k_band_bounds(const uint32_t *keys, int64_t n, int32_t *info)
@@ -2477,7 +2522,19 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
-    if (ctx->mid_hook) { const int hrc = ctx->mid_hook(s); if (hrc != ULTRA_OK) return hrc; }
+    // The caller's mid-run work on a lane beside the traceback's routing (two chains of small kernels, the chip is
+    // otherwise idle): the main stream takes it back in before the routing's copy to the host.
+    bool hook_beside = false;
+    if (ctx->mid_hook) {
+        hipStream_t hs = ctx->cfg.launch_lanes > 1 ? ctx->aux[0] : s;
+        if (hs != s) {
+            ULTRA_HIP_CHECK(ctx, hipEventRecord(ctx->fork_ev, s));
+            ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(hs, ctx->fork_ev, 0));
+        }
+        const int hrc = ctx->mid_hook(hs);
+        if (hrc != ULTRA_OK) return hrc;
+        if (hs != s) { ULTRA_HIP_CHECK(ctx, hipEventRecord(ctx->join_ev[0], hs)); hook_beside = true; }
+    }
     // ---- pass 3: first-location traceback ----
     a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
     a.ops_off = want_ops ? st.opsoff.as<int64_t>() : nullptr;
@@ -2508,16 +2565,17 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         int32_t *items_sorted = (int32_t *)(k_out + NH);
         const unsigned gb = (unsigned)((n_hits + 255) / 256);
         ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bandinfo.p, 0, 256, s));
-        hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in, st.bandinfo.as<int32_t>() + kBandBounds + kBandClasses);
+        hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in, st.bandinfo.as<int32_t>());
         {
             size_t tmp_bytes = 0;
-            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 4, s));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kTbKeyBits, s));
             ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
-            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kBandLBits + 4, s));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kTbKeyBits, s));
         }
-        hipLaunchKernelGGL(k_band_bounds, dim3(1), dim3(64), 0, s, k_out, n_hits, st.bandinfo.as<int32_t>());
+        hipLaunchKernelGGL(k_band_groups, dim3(1), dim3(64), 0, s, k_out, n_hits, st.bandinfo.as<int32_t>());
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
         int32_t h_info[kBandBounds + kBandClasses + kNumSizeClasses];
+        if (hook_beside) { ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->join_ev[0], 0)); hook_beside = false; }
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, sizeof h_info, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         hook_arrived = true;
@@ -2612,6 +2670,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     // 3b: full-height kernels for what is left (distance > 1014, or edit scripts wanted, or banding off).
     //     Their own scratch buffer, split between the classes that have work; the launches overlap with
     //     each other and with the banded ones (these are bound by their critical path, not by the ALUs).
+    if (hook_beside) { ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->join_ev[0], 0)); hook_beside = false; }
     const bool need_full = !use_band || h_band[kBandFallback] > 0;
     if (need_full) {
         struct FullPlan { int cls; int64_t region, items, begin, end, Lmax; int max_par; size_t entries; int nbb; };
