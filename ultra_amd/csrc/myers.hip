@@ -1754,17 +1754,20 @@ __global__ void k_gather_bounds(const int64_t *loc_off, const int64_t *hit_off, 
     if (i < np) { out[2 * i] = loc_off[pos[i]]; out[2 * i + 1] = hit_off[pos[i]]; }
 }
 // CSR fill: end columns kept in the first-pass slots, owner pair of every location, hit list
+// loc_cap: entries the location arrays hold (the launch that runs ahead of the host's knowledge of the total)
 __global__ void k_fill(const int32_t *ed, const int32_t *nloc, const int32_t *slots, int slot_cap,
                        const int64_t *loc_off, const int64_t *hit_off,
-                       int32_t *loc_end, int32_t *loc_pair, int32_t *hit_pairs, int32_t n)
+                       int32_t *loc_end, int32_t *loc_pair, int32_t *hit_pairs, int32_t n, int64_t loc_cap)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c = nloc[i];
     int64_t o = loc_off[i];
+    if (o + c > loc_cap) c = o < loc_cap ? (int)(loc_cap - o) : 0; // the host fills again once the arrays have grown
+    const bool in_slots = nloc[i] <= slot_cap;
     for (int a = 0; a < c; a++) {
         loc_pair[o + a] = i;
-        if (c <= slot_cap) loc_end[o + a] = slots[(int64_t)i * slot_cap + a];
+        if (in_slots) loc_end[o + a] = slots[(int64_t)i * slot_cap + a];
     }
     if (ed[i] >= 0) hit_pairs[hit_off[i]] = i;
 }
@@ -2388,6 +2391,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
                        st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), n);
     int64_t h_overflow[kBuckets] = {0, 0, 0, 0, 0};
     int32_t h_rerun[kBuckets] = {0, 0, 0, 0, 0}; // work items to run again without a limit on the end columns
+    const int64_t loc_cap = (int64_t)(std::min(st.locend.cap, std::min(st.locstart.cap, st.locpair.cap)) / 4);
     {
         // class boundaries (+ totals) to the host: one small copy, the only mid-batch synchronisation
         std::vector<int64_t> pos;
@@ -2403,7 +2407,15 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb.data(), dout, npz * 16, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_overflow, d_overflow, kBuckets * 8, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_rerun, st.bounds.as<int64_t>() + 120, kBuckets * 4, hipMemcpyDeviceToHost, s));
-        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        // The location arrays are filled while the totals travel to the host, into what the arrays hold from earlier
+        // batches; the host only waits for the copies (st.ev[1] serves as their marker until it is recorded for good).
+        if (loc_cap > 0) {
+            ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
+            hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, a.slots, a.slot_cap, a.loc_off,
+                               st.hitoff.as<int64_t>(), st.locend.as<int32_t>(), st.locpair.as<int32_t>(), st.hitpairs.as<int32_t>(), n, loc_cap);
+            ULTRA_HIP_CHECK(ctx, hipGetLastError());
+            ULTRA_HIP_CHECK(ctx, hipEventSynchronize(st.ev[1]));
+        } else ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         drain_b.dismiss();
         for (size_t c = 0; c < st.classes.size(); c++) {
             st.classes[c].lb = hb[2 * c]; st.classes[c].le = hb[2 * (c + 1)];
@@ -2412,11 +2424,14 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         st.total_loc = hb[2 * (npz - 1)]; st.total_hit = hb[2 * (npz - 1) + 1];
     }
     const size_t nl = (size_t)std::max<int64_t>(st.total_loc, 1);
-    ULTRA_HIP_CHECK(ctx, st.locend.ensure(nl * 4)); ULTRA_HIP_CHECK(ctx, st.locstart.ensure(nl * 4)); ULTRA_HIP_CHECK(ctx, st.locpair.ensure(nl * 4));
+    if ((int64_t)nl > loc_cap) { // first batch, or more locations than any batch before: the arrays grow, fill (again)
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // the launch that ran ahead still writes the old arrays
+        ULTRA_HIP_CHECK(ctx, st.locend.ensure(nl * 4)); ULTRA_HIP_CHECK(ctx, st.locstart.ensure(nl * 4)); ULTRA_HIP_CHECK(ctx, st.locpair.ensure(nl * 4));
+        hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, a.slots, a.slot_cap, a.loc_off,
+                           st.hitoff.as<int64_t>(), st.locend.as<int32_t>(), st.locpair.as<int32_t>(), st.hitpairs.as<int32_t>(), n, (int64_t)nl);
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    }
     a.loc_end = st.locend.as<int32_t>(); a.loc_start = st.locstart.as<int32_t>(); a.loc_pair = st.locpair.as<int32_t>();
-    hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, s, a.ed, a.nloc, a.slots, a.slot_cap, a.loc_off,
-                       st.hitoff.as<int64_t>(), a.loc_end, st.locpair.as<int32_t>(), st.hitpairs.as<int32_t>(), n);
-    ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare), and
     //      pass 2: start positions. ----
