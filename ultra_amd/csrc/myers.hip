@@ -53,6 +53,7 @@ struct MyArgs {
     int64_t begin, end;
     int32_t *wflag;  // forward launch: dense list of the work items in which some pair has more end columns than first-pass slots
     int32_t *wcount; // its length (one counter per register bucket)
+    int32_t bstride, boff; // myers_mega: workgroup x of this launch takes work item x * bstride + boff (a bucket's list dealt over two launches)
     // start pass: the work items of a launch follow from the location range of each size class, so they are
     // computed from blockIdx (heaviest class first) instead of being listed by the host
     struct { int32_t cls, first_block; int64_t b, e; } rr[4];
@@ -466,7 +467,7 @@ __device__ __forceinline__ void lane_item(const MyArgs &a, int64_t base, uint64_
         if (MODE == MODE_FWD) {
             if (it.valid) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
             const bool over = __any(it.valid && cnt > out_cap);
-            if (a.wflag && over && lane == 0) a.wflag[atomicAdd(a.wcount, 1)] = (int32_t)blockIdx.x;
+            if (a.wflag && over && lane == 0) a.wflag[atomicAdd(a.wcount, 1)] = (int32_t)blockIdx.x * a.bstride + a.boff;
         } else if (MODE == MODE_REV) {
             if (it.valid) a.loc_start[it.loc] = a.loc_end[it.loc] - last;
         } else if (MODE == MODE_NW) {
@@ -650,7 +651,7 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         if (MODE == MODE_FWD) {
             if (it.valid && g == G - 1) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
             const bool over = __any(it.valid && g == G - 1 && cnt > out_cap);
-            if (a.wflag && over && lane == 0) a.wflag[atomicAdd(a.wcount, 1)] = (int32_t)blockIdx.x;
+            if (a.wflag && over && lane == 0) a.wflag[atomicAdd(a.wcount, 1)] = (int32_t)blockIdx.x * a.bstride + a.boff;
         } else if (MODE == MODE_REV) {
             if (it.valid && g == G - 1) a.loc_start[it.loc] = a.loc_end[it.loc] - last;
         } else if (MODE == MODE_NW) {
@@ -693,20 +694,21 @@ template <int MODE, int BUCKET>
 __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list, int32_t n)
 {
     extern __shared__ uint64_t lds[];
-    if ((int32_t)blockIdx.x >= n) return;
+    const int32_t item = (int32_t)blockIdx.x * a.bstride + a.boff;
+    if (item >= n) return;
     WorkItem wi;
-    if (MODE == MODE_FWD_EXACT) wi = list[a.wflag[blockIdx.x]]; // the forward launch over the same list left these
-    else if (list) wi = list[blockIdx.x];
+    if (MODE == MODE_FWD_EXACT) wi = list[a.wflag[item]]; // the forward launch over the same list left these
+    else if (list) wi = list[item];
     else {
         // constant indices only: a dynamically indexed member would move the whole argument block into scratch memory
         int32_t cls = a.rr[0].cls, first = a.rr[0].first_block;
         int64_t rb = a.rr[0].b, re = a.rr[0].e;
 #pragma unroll
         for (int t = 1; t < 4; t++)
-            if (t < a.n_rr && (int32_t)blockIdx.x >= a.rr[t].first_block) { cls = a.rr[t].cls; first = a.rr[t].first_block; rb = a.rr[t].b; re = a.rr[t].e; }
+            if (t < a.n_rr && item >= a.rr[t].first_block) { cls = a.rr[t].cls; first = a.rr[t].first_block; rb = a.rr[t].b; re = a.rr[t].e; }
         wi.cls = cls;
         const int per = wi.cls < 4 ? 64 : wi.cls < 6 ? 32 : wi.cls < 8 ? 16 : wi.cls < 10 ? 8 : 1; // 64 / G of the class
-        wi.base = rb + (int64_t)((int32_t)blockIdx.x - first) * per;
+        wi.base = rb + (int64_t)(item - first) * per;
         wi.end = re;
         wi.cost = 0;
     }
@@ -1844,13 +1846,17 @@ constexpr int kBuckets = 5;
 inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 10 ? 3 : 4; }
 inline int bucket_wmax(int b) { return b == 0 ? 2 : b < 4 ? 4 : 8; } // words per lane: LDS per wavefront = S * wmax * 512 B
 
-template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket, const WorkItem *d_list, int32_t n)
+// part / parts: this launch takes every parts-th work item of the list starting with item `part`, on lane `lane_i`
+template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket, const WorkItem *d_list, int32_t n, int part = 0, int parts = 1, int lane_i = -1)
 {
     if (n <= 0) return hipSuccess;
+    a.bstride = parts; a.boff = part;
+    const int32_t blocks = (n - part + parts - 1) / parts;
+    if (blocks <= 0) return hipSuccess;
     a.wflag = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ctx->my.buckets[bucket].fwd_flag.as<int32_t>() : nullptr;
     a.wcount = (int32_t *)(ctx->my.bounds.as<int64_t>() + 120) + bucket;
     const size_t shmem = (size_t)a.S * bucket_wmax(bucket) * 64 * sizeof(uint64_t);
-    hipStream_t cs = ctx->lane(bucket);
+    hipStream_t cs = ctx->lane(lane_i >= 0 ? lane_i : bucket);
     const void *fn = bucket == 0 ? (const void *)myers_mega<MODE, 0> : bucket == 1 ? (const void *)myers_mega<MODE, 1>
                    : bucket == 2 ? (const void *)myers_mega<MODE, 2> : bucket == 3 ? (const void *)myers_mega<MODE, 3>
                                                                                      : (const void *)myers_mega<MODE, 4>;
@@ -1859,11 +1865,11 @@ template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket,
         if (e != hipSuccess) return e;
     }
     switch (bucket) {
-    case 0: hipLaunchKernelGGL((myers_mega<MODE, 0>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
-    case 1: hipLaunchKernelGGL((myers_mega<MODE, 1>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
-    case 2: hipLaunchKernelGGL((myers_mega<MODE, 2>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
-    case 3: hipLaunchKernelGGL((myers_mega<MODE, 3>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
-    default: hipLaunchKernelGGL((myers_mega<MODE, 4>), dim3((unsigned)n), dim3(64), shmem, cs, a, d_list, n); break;
+    case 0: hipLaunchKernelGGL((myers_mega<MODE, 0>), dim3((unsigned)blocks), dim3(64), shmem, cs, a, d_list, n); break;
+    case 1: hipLaunchKernelGGL((myers_mega<MODE, 1>), dim3((unsigned)blocks), dim3(64), shmem, cs, a, d_list, n); break;
+    case 2: hipLaunchKernelGGL((myers_mega<MODE, 2>), dim3((unsigned)blocks), dim3(64), shmem, cs, a, d_list, n); break;
+    case 3: hipLaunchKernelGGL((myers_mega<MODE, 3>), dim3((unsigned)blocks), dim3(64), shmem, cs, a, d_list, n); break;
+    default: hipLaunchKernelGGL((myers_mega<MODE, 4>), dim3((unsigned)blocks), dim3(64), shmem, cs, a, d_list, n); break;
     }
     return hipGetLastError();
 }
@@ -2367,7 +2373,16 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         if (bk.n_fwd <= 0) continue;
         hipStream_t cs = ctx->lane(b);
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev0, cs));
-        ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd));
+        // The workgroup dispatcher deals the chip's slots about evenly over the launches in flight, not by their work:
+        // the bucket of the three- and four-word lane classes (m = 129 .. 256 against long targets) finished 1.5 - 2 ms
+        // after the others.  With lanes to spare its list is dealt over three launches (interleaved, so each keeps the
+        // heaviest-first order) and takes three shares: the buckets then end within a millisecond of each other
+        // (measured: forward phase 13.0 -> 12.4 ms; a second launch for the lane groups' bucket as well: 12.6).
+        if (ctx->cfg.launch_lanes >= kBuckets + 3 && b == 1 && bk.n_fwd >= 64) {
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 0, 3));
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 1, 3, kBuckets));
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 2, 3, kBuckets + 1));
+        } else ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd));
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev1, cs));
     }
     ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
