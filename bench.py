@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--batches", type=int, default=4, help="distinct batches per GPU (default: 4 x 262144 = 1M reads)")
     ap.add_argument("--preset", default="ont_cdna", choices=["ont_cdna", "isoseq", "ont_drna"])
     ap.add_argument("--world", default="c3", choices=["c3", "c2", "small"])
+    ap.add_argument("--rehearse", action="store_true",
+                    help="every rank on GPU 0, rendezvous over gloo: runs the multi-rank path (batches dealt over the ranks, "
+                         "barriers, max / sum over the ranks) on a one-GPU box; the value it prints is not a measurement")
     ap.add_argument("--genes", type=int, default=0, help="override the annotation's gene count")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (0 = skip)")
     ap.add_argument("--e2e-rounds", type=int, default=4, help="passes over the batches through ultra_pipe (0 = skip)")
@@ -193,9 +196,15 @@ def main():
     from ultra_amd import lib
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if args.rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    red_dev = "cuda" if world > 1 and not args.rehearse else None
     cfg = {}
     if args.lanes:
         cfg["launch_lanes"] = args.lanes
@@ -247,7 +256,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     K = args.steps
-    elapsed, reads_all, cells_all = shard.reduce_job(elapsed, args.reads * K, cells_run, device="cuda" if world > 1 else None)
+    elapsed, reads_all, cells_all = shard.reduce_job(elapsed, args.reads * K, cells_run, device=red_dev)
 
     # ---- results back to the host (PCIe; outside the timed region) + parity spot check against the oracle ----
     t1 = time.perf_counter()
@@ -313,7 +322,7 @@ def main():
                 pipe.release(); done += 1
             barrier()
             secs = time.perf_counter() - t0
-            secs, n_reads, _ = shard.reduce_job(secs, args.reads * total, 0.0, device="cuda" if world > 1 else None)
+            secs, n_reads, _ = shard.reduce_job(secs, args.reads * total, 0.0, device=red_dev)
             avg = lambda k: sum(t[k] for t in tims) / len(tims)
             return n_reads / secs, total, chains, {"stage_h2d_device_plan_sort": avg("stage_ms"), "waiting_for_gpu": avg("wait_ms"),
                                                    "run": avg("run_ms"), "fetch_d2h": avg("fetch_ms")}
@@ -395,7 +404,8 @@ def main():
                                       P["err"], int(np.mean([rs.reads.size / max(len(rs), 1) for rs in sets])), nb, args.reads),
                        "reads_per_gpu_per_step": args.reads, "distinct_batches_per_gpu": nb, "pairs_per_step_per_gpu": n_pairs,
                        "candidates_per_step_per_gpu": n_cands, "cells_per_step_per_gpu": cells_step, "cells_per_read": cells_step / args.reads,
-                       "hw_queues": HW_QUEUES, "parallelism": "batches dealt over %d rank(s), no collective" % world},
+                       "hw_queues": HW_QUEUES, "parallelism": "batches dealt over %d rank(s), no collective" % world,
+                       **({"rehearsal": "all ranks share GPU 0, gloo rendezvous: the path is exercised, the value is not a measurement"} if args.rehearse else {})},
             "myers_gcups_forward": cells_all / (acc["fwd"] * 1e-3) * 1e-9 / world if acc["fwd"] > 0 else None,
             "myers_gcups_all_passes": cells_all / (acc["all"] * 1e-3) * 1e-9 / world if acc["all"] > 0 else None,
             "stage_ms_per_step": {"myers_forward": acc["fwd"] / K, "myers_starts": acc["rev"] / K, "myers_traceback": acc["tb"] / K,
