@@ -1611,6 +1611,7 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
     if (threadIdx.x < kBandClasses + kNumSizeClasses) top[threadIdx.x] = 0;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int slot = -1, v = 0;
     if (i < n_hits) {
         const int32_t p = a.hit_pairs[i];
         const int ed = a.ed[p];
@@ -1619,7 +1620,6 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
         // ed + 1 diagonals, one spare on either side, up to 7 lost to the window's 8-row alignment: ed <= 64 WB - 10
         uint32_t c = 0;
         while (c < kBandFallback && ed > band_rows((int)c) - 10) c++;
-        int slot, v;
         if (c < kBandFallback) {
             keys[i] = c * kTbBins + (kTbBins - 1 - tb_length_bin(L));
             slot = (int)c; v = (int)L;
@@ -1628,7 +1628,16 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
             keys[i] = kBandClasses * kTbBins + sc * kTbFullBins + (kTbFullBins - 1 - (tb_length_bin(L) >> 5));
             slot = kBandClasses + (int)sc; v = ed;
         }
-        if (v > top[slot]) atomicMax(&top[slot], v);
+    }
+    {
+        // nearly every lane of a wavefront has the slot of its first lane: one LDS atomic for them all (every lane takes
+        // part in the exchange, the ones past the end with no slot), the others on their own
+        const int slot0 = __shfl(slot, 0, 64);
+        int vm = slot == slot0 ? v : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(vm, o, 64); vm = t > vm ? t : vm; }
+        if ((threadIdx.x & 63) == 0 && slot0 >= 0 && vm > top[slot0]) atomicMax(&top[slot0], vm);
+        if (slot >= 0 && slot != slot0 && v > top[slot]) atomicMax(&top[slot], v);
     }
     __syncthreads();
     if (threadIdx.x < kBandClasses + kNumSizeClasses) {
