@@ -479,8 +479,9 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     memset(m.pinned_base, 0, ((size_t)ni + 1) * 8);
     m.h_instbase.clear();
     // ---- slot layout: one slot per location of a candidate's pair (+1 for its contained-read pair).  It only needs
-    //      the forward pass, so it is enqueued from inside the Myers run (behind the start pass) and its total
-    //      comes back with that run's next host synchronisation. ----
+    //      the forward pass, so it is enqueued from inside the Myers run (behind the start pass, on the stream the run
+    //      names: a lane beside the traceback's routing) and its totals come back with that run's next host
+    //      synchronisation. ----
     ctx->mid_hook = [ctx, &m, &my, nc, ni](hipStream_t s) -> int {
         if (ni == 0) return ULTRA_OK;
         if (nc > 0) {
