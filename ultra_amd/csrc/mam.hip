@@ -67,6 +67,10 @@ __device__ __forceinline__ double pair_accuracy(const MamArgs &a, int p, int &sp
 struct CandData {
     int kind, es, ee, p, pc, nl, ed, seq_len;
     int64_t lo, cap_off;
+    // accuracies of the candidate's pair and of its contained-read pair (with the latter's first span), computed once
+    // per load: every pass over the candidate needs them, each behind four dependent loads and an FP64 division
+    double acc, acc_c;
+    int s0_c, ed_c;
 };
 __device__ __forceinline__ CandData load_cand(const MamArgs &a, int c)
 {
@@ -74,7 +78,15 @@ __device__ __forceinline__ CandData load_cand(const MamArgs &a, int c)
     d.kind = a.kind[c]; d.es = a.e_start[c]; d.ee = a.e_stop[c]; d.p = a.pair[c]; d.pc = a.pairc[c];
     d.seq_len = a.seq_len[c]; d.cap_off = a.cap_off[c];
     d.nl = 0; d.ed = -1; d.lo = 0;
-    if (d.p >= 0) { d.nl = a.nloc[d.p]; d.ed = a.ed[d.p]; d.lo = a.loc_off[d.p]; }
+    d.acc = 0.0; d.acc_c = 0.0; d.s0_c = 0; d.ed_c = -1;
+    if (d.p >= 0) {
+        d.nl = a.nloc[d.p]; d.ed = a.ed[d.p]; d.lo = a.loc_off[d.p];
+        if (d.ed >= 0 && d.ee - d.es >= 9) { int s0; d.acc = pair_accuracy(a, d.p, s0); }
+    }
+    if (d.pc >= 0) {
+        d.ed_c = a.ed[d.pc];
+        if (d.ed_c >= 0) d.acc_c = pair_accuracy(a, d.pc, d.s0_c);
+    }
     return d;
 }
 
@@ -112,7 +124,7 @@ __device__ int walk(const MamArgs &a, const CandData &cd, int c, int read_len, A
         if (width >= 9) { // approximate hit (:311-349)
             bool ok = false;
             double acc = 0.0;
-            if (ed >= 0) { int s0; acc = pair_accuracy(a, p, s0); ok = acc > a.min_acc; }
+            if (ed >= 0) { acc = cd.acc; ok = acc > a.min_acc; }
             double last = 0.0;
             int smax = -1;
             for (int i = 0; i < nl; i++) {
@@ -152,16 +164,8 @@ __device__ int walk(const MamArgs &a, const CandData &cd, int c, int read_len, A
     }
     const int pc = cd.pc;
     if (pc >= 0) { // read contained in the segment (:374-402)
-        if (MODE == MODE_COUNT) {
-            bool ok = false;
-            if (a.ed[pc] >= 0) { int s0; ok = pair_accuracy(a, pc, s0) > a.min_acc; }
-            flag[nl] = ok ? 1 : 0;
-        }
-        if (flag[nl]) {
-            int s0;
-            const double acc = pair_accuracy(a, pc, s0);
-            take(0, read_len - 1, acc * (double)s0, s0);
-        }
+        if (MODE == MODE_COUNT) flag[nl] = (cd.ed_c >= 0 && cd.acc_c > a.min_acc) ? 1 : 0;
+        if (flag[nl]) take(0, read_len - 1, cd.acc_c * (double)cd.s0_c, cd.s0_c);
     }
     return cnt;
 }
