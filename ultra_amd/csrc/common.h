@@ -98,6 +98,7 @@ struct MamState {
     float ms[3] = {0, 0, 0}; // MAM build, chaining, chain gather
     std::vector<int64_t> h_instbase;
     std::vector<int32_t> h_nmam;
+    bool nmam_on_host = false;       // h_nmam holds the last run's counts (read back only when something needs them)
     int64_t *pinned_base = nullptr;  // pinned copy of instbase (first MAM slot of every instance, then the total), read
     size_t pinned_cap = 0;           // back while the Myers passes still run; entries
     std::vector<int32_t> h_slots;    // slots per instance = upper bound of its MAM count

@@ -330,6 +330,20 @@ __global__ void k_gather_i64(const int64_t *src, const int64_t *pos, int64_t *ds
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[pos[i]];
 }
+// one block: out[0] = sum of v (the batch's MAM total; the per-instance counts stay on the device until a fetch wants them)
+__global__ void __launch_bounds__(1024) k_sum_i32(const int32_t *v, int32_t n, int64_t *out)
+{
+    __shared__ int64_t part[1024];
+    int64_t acc = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += v[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
 __global__ void k_widen(const int32_t *in, uint64_t *out, int32_t n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -595,14 +609,18 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     hipLaunchKernelGGL(k_chain_gather, dim3((ni + 3) / 4), dim3(256), 0, s, g);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[4], s));
-    int64_t h_total = 0;
+    int64_t h_total = 0, h_mams = 0;
     int32_t status = 0;
+    // the scan above is done with its scratch by now (stream order): its first word takes the MAM total
+    hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(1024), 0, s, m.nmam.as<int32_t>(), ni, m.scantmp.as<int64_t>());
+    ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_total, m.chainoff.as<int64_t>() + ni, 8, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_mams, m.scantmp.p, 8, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
-    if (!exact_needed) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
     if (my.times_pending) { const int trc = ultra_myers_collect_times(ctx); if (trc != ULTRA_OK) return trc; }
-    for (int32_t i = 0; i < ni; i++) m.total_mam += m.h_nmam[(size_t)i];
+    m.total_mam = h_mams;
+    m.nmam_on_host = exact_needed; // otherwise the counts are copied when a fetch asks for the MAM lists
     if (status != 0)
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_run: an instance reached the reference's 'BUG' state in the n log n chainer");
     m.total_chain = h_total;
@@ -708,7 +726,7 @@ extern "C" int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out)
             ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->chain_chr, m.cchr.p, TC * 4, hipMemcpyDeviceToHost, s));
         }
     }
-    memcpy(out->n_mam, m.h_nmam.data(), (size_t)ni * 4);
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(out->n_mam, m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
     // optional: every instance's full, filtered and sorted MAM list (tests compare MAM sets)
     if (out->mam_off) {
         if (out->mam_cap < m.total_mam)
@@ -730,7 +748,12 @@ extern "C" int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out)
         }
         m.h_instbase.resize((size_t)ni + 1);
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_instbase.data(), m.instbase.p, ((size_t)ni + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (!m.nmam_on_host) {
+            m.h_nmam.resize((size_t)ni);
+            ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
+        }
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        m.nmam_on_host = true;
         int64_t w = 0;
         for (int32_t i = 0; i < ni; i++) {
             out->mam_off[i] = w;
