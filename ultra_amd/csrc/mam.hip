@@ -498,7 +498,6 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
         ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&m.pinned_base, ((size_t)ni + 1 + 64) * 8, hipHostMallocDefault));
         m.pinned_cap = (size_t)ni + 1 + 64;
     }
-    memset(m.pinned_base, 0, ((size_t)ni + 1) * 8);
     m.h_instbase.clear();
     // ---- slot layout: one slot per location of a candidate's pair (+1 for its contained-read pair).  It only needs
     //      the forward pass, so it is enqueued from inside the Myers run (behind the start pass, on the stream the run
@@ -518,6 +517,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
         } else {
             ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.instbase.p, 0, ((size_t)ni + 1) * 8, s));
             ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.capoff.p, 0, 8, s));
+            memset(m.pinned_base, 0, ((size_t)ni + 1) * 8); // no candidates: no slots, and no copy that would say so
         }
         return ULTRA_OK;
     };
