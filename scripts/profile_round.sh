@@ -5,7 +5,7 @@
 # profiler initialises HIP before bench.py could set it.
 set -o pipefail
 tag=${1:-r01}
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8
+export TMPDIR=/tmp GPU_MAX_HW_QUEUES=16
 out=gpurun_out/prof_$tag
 mkdir -p $out
 B="python3 bench.py --steps 10 --warmup 2 --cpu-seconds 0 --check 0 --e2e-rounds 0 --micro 0"
