@@ -207,9 +207,10 @@ def test_align_single_equals_the_reference_on_sirv(ctx, tmp_path, gpu_batch):
     assert used["sam_entry"] == set(calls["sam_entry"]) and used["exact_alignment"] == set(calls["exact_alignment"])
 
 
-def test_pc_main_runs_the_reference_protocol(ctx, tmp_path):
+@pytest.mark.parametrize("per_gpu", [1, 2])
+def test_pc_main_runs_the_reference_protocol(ctx, tmp_path, per_gpu):
     """ultra_amd.pc.main(reads, seeds, outfile, args) as uLTRA:382 calls it: a producer zipping the reads file with the
-    seed file into 1000-read queue batches, one align_single consumer PROCESS per GPU reading the index pickles from
+    seed file into 1000-read queue batches, one (or args.consumers_per_gpu) align_single consumer PROCESS per GPU reading the index pickles from
     args.outfolder, SAM rows appended to the output file, the 8-entry totals returned.  Same rows as align_single run
     in this process on the same records (base-level alignment on the GPU in both)."""
     from tests import helpers
@@ -229,7 +230,8 @@ def test_pc_main_runs_the_reference_protocol(ctx, tmp_path):
     open(sam_path, "w").close()
     down = align.Downstream(helpers.stub_find_exons, helpers.stub_classify, None, helpers.stub_sam_entry)
     args = types.SimpleNamespace(outfolder=out, index=out, reduce_read_ployA=20, max_intron=1200000, dropoff=0.95, max_loc=5, min_acc=0.6,
-                                 alignment_threshold=0.5, non_covered_cutoff=15, gpus=1, gpu_batch_reads=1500, downstream=down)
+                                 alignment_threshold=0.5, non_covered_cutoff=15, gpus=1, gpu_batch_reads=1500, downstream=down,
+                                 consumers_per_gpu=per_gpu)
     totals = pc.main(reads_path, seeds_path, sam_path, args)
     rows = open(sam_path).read().splitlines(True)
     # the same records through align_single in this process

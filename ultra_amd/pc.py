@@ -53,7 +53,7 @@ def _drain(outfile, output_sam_buffer):
         n += len(rows)
 
 
-def file_IO(input_queue, reads, seeds, output_sam_buffer, outfile_name, n_consumers=1):
+def file_IO(input_queue, reads, seeds, output_sam_buffer, outfile_name):
     """Producer (pc.py:27-62): zips the reads with their seed records into 1000-read batches."""
     written = 0
     with open(outfile_name, "a") as outfile:
@@ -74,10 +74,10 @@ def file_IO(input_queue, reads, seeds, output_sam_buffer, outfile_name, n_consum
     return written
 
 
-def _consumer(rank, input_queue, output_sam_buffer, counts_queue, args):
-    os.environ["LOCAL_RANK"] = str(rank)        # before anything touches HIP in this process
+def _consumer(process_id, device, input_queue, output_sam_buffer, counts_queue, args):
+    os.environ["LOCAL_RANK"] = str(device)      # before anything touches HIP in this process
     from . import align
-    align.align_single(rank, input_queue, output_sam_buffer, counts_queue, args)
+    align.align_single(process_id, input_queue, output_sam_buffer, counts_queue, args)
 
 
 def main(reads, seeds, outfile, args):
@@ -92,9 +92,13 @@ def main(reads, seeds, outfile, args):
     input_queue = manager.Queue(200)
     output_sam_buffer = manager.Queue()
     counts_queue = manager.Queue()
-    producer = ctx.Process(target=file_IO, args=(input_queue, reads, seeds, output_sam_buffer, outfile, n_gpus))
+    producer = ctx.Process(target=file_IO, args=(input_queue, reads, seeds, output_sam_buffer, outfile))
     producer.start()
-    workers = [ctx.Process(target=_consumer, args=(r, input_queue, output_sam_buffer, counts_queue, args)) for r in range(n_gpus)]
+    # consumers per GPU (default 1): the stages behind the MAM stage are the reference's own Python, and a second
+    # process on the same card runs its host part while the first one's batch is on the device
+    per_gpu = max(1, int(getattr(args, "consumers_per_gpu", 1) or 1))
+    workers = [ctx.Process(target=_consumer, args=(i, i // per_gpu, input_queue, output_sam_buffer, counts_queue, args))
+               for i in range(n_gpus * per_gpu)]
     for w in workers:
         w.start()
     for w in workers:
