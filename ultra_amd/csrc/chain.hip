@@ -90,13 +90,18 @@ constexpr int kQuadSmall = 256;    // LDS entries per wave in the 4-waves-per-bl
 
 // Launch lists by size on the device.  Segment of an instance: 0 .. kTiny = lane-per-instance kernel, largest first
 // (segment kTiny - n), then the small quadratic launch, the large one, the n log n solver.
-constexpr int kSegSmall = kTiny + 1, kSegBig = kTiny + 2, kSegTree = kTiny + 3, kSegEnd = kTiny + 4;
+// The small quadratic launch (one wavefront per instance of 49 .. 256 MAMs, up to a millisecond for the largest) gets
+// kSmallBins segments by size, largest first: the launch's critical path starts with the launch, not in its tail.
+constexpr int kSmallBins = 8;
+constexpr int kSegSmall = kTiny + 1, kSegBig = kSegSmall + kSmallBins, kSegTree = kSegBig + 1, kSegEnd = kSegTree + 1;
+static_assert(kSegEnd + 1 <= 64, "segment bounds live in 64 words");
 __global__ void __launch_bounds__(256) k_chain_keys(const int32_t *cnt, int32_t n_inst, int32_t switch_n, uint32_t *keys)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inst) return;
     const int n = cnt[i];
-    keys[i] = n > switch_n && n > 0 ? kSegTree : n <= kTiny ? (uint32_t)(kTiny - (n < 0 ? 0 : n)) : n <= kQuadSmall ? kSegSmall : kSegBig;
+    keys[i] = n > switch_n && n > 0 ? kSegTree : n <= kTiny ? (uint32_t)(kTiny - (n < 0 ? 0 : n))
+            : n <= kQuadSmall ? (uint32_t)(kSegSmall + (kQuadSmall - n) * kSmallBins / (kQuadSmall - kTiny)) : kSegBig;
 }
 struct ListSlice { const int32_t *list; int n; };
 __device__ __forceinline__ ListSlice list_slice(const ChainArgs &a)
