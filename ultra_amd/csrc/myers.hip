@@ -2640,7 +2640,10 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             region[c] = chunks * (2 + np) * band_rows(c) / band_group(c); // 64-bit words per wavefront: 64 lanes x (rows / 64 / lanes per hit) words each
             const int per_wave = 64 / band_group(c); // hits per wavefront
             const int64_t waves = ((int64_t)h_band[c] + per_wave - 1) / per_wave;
-            int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * (c == 0 ? 20 : 10));
+            // Far more wavefronts than fit at once (the LDS of a CU holds ten): short-lived ones keep the eight launches of
+            // the phase balanced as slots come free (measured: 20 / 10 per CU 4.25 ms, 80 / 40 4.16, 160 / 80 4.11, 320 / 160
+            // 4.11; 4 / 2 - about what is resident - 5.7).  The scratch budget below still caps them.
+            int64_t u = std::min<int64_t>(waves, (int64_t)ctx->prop.multiProcessorCount * (c == 0 ? 160 : 80));
             u = std::min<int64_t>(u, std::max<int64_t>(1, (int64_t)((budget / kBandClasses) / (size_t)(region[c] * 8))));
             units[c] = u;
             total_words += (size_t)region[c] * (size_t)u;
