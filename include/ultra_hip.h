@@ -29,7 +29,7 @@ extern "C" {
 #define ULTRA_E_ARG (-1)         /* bad argument (null pointer, negative length, offsets out of range) */
 #define ULTRA_E_HIP (-2)         /* a HIP runtime call failed */
 #define ULTRA_E_CAPACITY (-3)    /* a caller-sized output is too small; the needed size is reported */
-#define ULTRA_E_UNSUPPORTED (-4) /* input outside the supported envelope (more than 36 distinct bytes in a batch, query > 32768) */
+#define ULTRA_E_UNSUPPORTED (-4) /* input outside the supported envelope (more than 36 distinct bytes in a batch) */
 #define ULTRA_E_NODEVICE (-5)    /* no usable gfx950 device */
 #define ULTRA_E_STATE (-6)       /* _run/_fetch called without a staged batch */
 
@@ -118,6 +118,13 @@ int ultra_myers_fetch(ultra_ctx *ctx, int32_t *ed, int32_t *n_loc, int64_t *loc_
  * kernels alone (the concurrent myers_mega<FWD, bucket> launches, first start to last end).  Measured with
  * HIP events on the streams the kernels are launched on. */
 int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[5]);
+/* Cell accounting of the staged batch.  edlib.align(..., k) as the reference calls it (classify_read_with_mams.py:312:
+ * k = 0.4 * min(len(read), len(seq))) returns -1 for a query more than k bases longer than its target after a few
+ * columns - its band never reaches the last row.  The library answers those pairs (ed = -1, no locations) when the
+ * batch is staged; no kernel sees them.  *cells_computed = sum of q_len * t_len over the pairs the forward pass runs
+ * (what ultra_myers_last_timing reports and every GCUPS figure is taken over), *cells_skipped = the same sum over the
+ * pairs answered without a launch, *pairs_skipped their number. */
+int ultra_myers_cell_counts(const ultra_ctx *ctx, double *cells_computed, double *cells_skipped, int64_t *pairs_skipped);
 /* Per register bucket of the last _run (a bucket = one forward kernel, myers_mega<FWD, bucket>, covering
  * the size classes up to W 64-row words per lane; bucket 3 = multi-lane classes for queries > 512):
  * G[i] = bucket id, W[i] = its widest class, forward-pass cells of its pairs and device milliseconds

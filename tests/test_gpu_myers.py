@@ -214,3 +214,83 @@ def test_wide_lane_group_bands(ctx, mix):
             if (ed <= lim).any() and (ed > lim).any():
                 seen.add(lim)
     assert {374, 502} <= seen and (758 in seen or mix[0] == 1.0)   # deletions alone stay below 758 at these lengths
+
+
+def _pack(pairs):
+    """[(query, target, k)] of str -> the arrays of ultra_myers_hw_batch."""
+    chunks, size, q_off, q_len, t_off, t_len, ks = [], 0, [], [], [], [], []
+    for q, t, k in pairs:
+        for s, offs, lens in ((q, q_off, q_len), (t, t_off, t_len)):
+            offs.append(size); lens.append(len(s)); chunks.append(s.encode()); size += len(s)
+        ks.append(k)
+    return (np.frombuffer(b"".join(chunks), dtype=np.uint8), np.array(q_off, np.int64), np.array(q_len, np.int32),
+            np.array(t_off, np.int64), np.array(t_len, np.int32), np.array(ks, np.int32))
+
+
+def test_length_prefilter_on_both_sides_of_the_bound(ctx):
+    """A query more than k bases longer than its target cannot be a hit (distance >= m - n): the library answers those
+    pairs when the batch is staged and no kernel sees them (ultra_myers_cell_counts).  Pairs on either side of
+    m - n = k, in every size class, with queries that DO reach distance m - n (the target with bases spliced in), so
+    that the pair next to the bound is a hit and the one beyond is not: results equal the oracle's either way."""
+    from oracle import cport
+    rng = np.random.RandomState(41)
+    pairs, expect_skipped = [], 0
+    for n in (12, 60, 130, 250, 400, 700, 1500, 2500, 5000):
+        for extra in (1, 7, n // 3, n // 2):
+            t = helpers.rand_seq(rng, n)
+            q = list(t)
+            for _ in range(extra):
+                q.insert(int(rng.randint(0, len(q) + 1)), "ACGT"[rng.randint(0, 4)])
+            q = "".join(q)
+            for k in (extra - 2, extra - 1, extra, extra + 1, int(0.4 * n), -1, len(q) + 5):
+                pairs.append((q, t, k))
+                ke = len(q) if (k < 0 or k > len(q)) else k
+                expect_skipped += (len(q) - n) > ke
+            pairs.append((helpers.rand_seq(rng, n + extra), t, int(0.4 * n)))        # the reference's k, unrelated query
+            expect_skipped += extra > int(0.4 * n)
+    packed = _pack(pairs)
+    got = _check(ctx, packed)
+    assert (got["ed"] >= 0).sum() > 100 and (got["ed"] < 0).sum() > 100
+    ctx.myers_stage(*packed)
+    computed, skipped, n_skipped = ctx.myers_cell_counts()
+    assert n_skipped == expect_skipped and 0 < n_skipped < len(pairs)
+    arena, q_off, q_len, t_off, t_len, k = packed
+    ke = np.where((k < 0) | (k > q_len), q_len, k)
+    sk = (q_len - t_len) > ke
+    cells = q_len.astype(np.float64) * t_len
+    assert computed == cells[~sk].sum() and skipped == cells[sk].sum()
+    ctx.myers_run()
+    again = ctx.myers_fetch()
+    assert np.array_equal(again["ed"], got["ed"]) and np.array_equal(again["loc_start"], got["loc_start"])
+    assert (again["ed"][sk] == -1).all() and (again["n_loc"][sk] == 0).all()
+    # and the oracle, which computes every cell, agrees that none of them is a hit
+    lo = np.arange(len(k) + 1, dtype=np.int64) * 64
+    assert (cport.hw_batch(arena, q_off, q_len, t_off, t_len, k, lo)[0][sk] == -1).all()
+
+
+def test_queries_beyond_32768_rows(ctx):
+    """Queries longer than the widest wavefront-per-pair class (32768 rows) run in strips of 32768 rows (one
+    wavefront, strip after strip, the row between two strips handed over through HBM): a 40 kb read contained in a
+    50 kb exon (classify_read_with_mams.py:374-377), the 50 kb exon as the query against the read (:312; m - n = 10 kb
+    is below k = 16 kb, so the pair is not answered by length), a 70 kb query (three strips), low and high error rates
+    (banded and full-height traceback), in an otherwise ordinary batch."""
+    rng = np.random.RandomState(43)
+    seg = helpers.rand_seq(rng, 50000)
+    read = helpers.mutate(rng, seg[6000:46000], 0.07)
+    clean = helpers.mutate(rng, seg[1000:41000], 0.01)
+    big_t = helpers.rand_seq(rng, 72000)
+    big_q = helpers.mutate(rng, big_t[500:70500], 0.008)
+    pairs = [(read, seg, int(0.4 * len(read))),       # contained read, ~2800 edits: full-height traceback in strips
+             (seg, read, int(0.4 * len(read))),       # the exon as the query: a hit through ~11 k inserted bases
+             (clean, seg, int(0.4 * len(clean))),     # ~400 edits: banded traceback
+             (big_q, big_t, int(0.4 * len(big_q))),   # three strips
+             (helpers.rand_seq(rng, 33000), helpers.rand_seq(rng, 34000), -1),  # unrelated, unbounded k: hit with a huge distance
+             (seg[:32769], seg[100:33100], 4000)]     # one row into the second strip
+    normal = helpers.make_pairs(rng, 300, (9, 2600), (200, 3000), kmode="ref", planted=0.7)
+    na, nqo, nql, nto, ntl, nk = normal
+    for p in range(len(nk)):
+        pairs.append((bytes(na[nqo[p]:nqo[p] + nql[p]]).decode(), bytes(na[nto[p]:nto[p] + ntl[p]]).decode(), int(nk[p])))
+    order = rng.permutation(len(pairs))
+    got = _check(ctx, _pack([pairs[i] for i in order]))
+    ed = got["ed"][np.argsort(order)]
+    assert ed[0] > 1014 and ed[1] > 10000 and 0 < ed[2] <= 1014 and 0 < ed[3] <= 1014 and ed[4] > 10000 and ed[5] >= 0

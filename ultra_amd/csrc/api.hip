@@ -129,6 +129,15 @@ int ultra_myers_last_timing(const ultra_ctx *ctx, double *cells, float ms[5])
     return ULTRA_OK;
 }
 
+int ultra_myers_cell_counts(const ultra_ctx *ctx, double *cells_computed, double *cells_skipped, int64_t *pairs_skipped)
+{
+    if (!ctx || !ctx->my.staged) return ULTRA_E_STATE;
+    if (cells_computed) *cells_computed = ctx->my.cells;
+    if (cells_skipped) *cells_skipped = ctx->my.cells_skipped;
+    if (pairs_skipped) *pairs_skipped = ctx->my.n_skipped;
+    return ULTRA_OK;
+}
+
 int ultra_myers_class_timing(const ultra_ctx *ctx, int32_t cap, int32_t *G, int32_t *W, double *cells, float *fwd_ms,
                              int32_t *n_classes)
 {

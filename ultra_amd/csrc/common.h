@@ -32,9 +32,11 @@ struct DevBuf {
 
 // One size class of the Myers kernels: G lanes per pair, W 64-row blocks per lane.
 struct MyersClass {
+    int cls;            // index into the class table (14 = the long class: strips of 32768 rows)
     int G, W;           // rows covered = 64*G*W
     int64_t pb, pe;     // pair range (sorted order)
     int32_t max_t;      // longest target in the class
+    int32_t max_m;      // longest query in the class
     int64_t lb, le;     // location (CSR) range, known after the forward pass
     int64_t hb, he;     // hit (ed >= 0) range
     double cells;       // forward-pass cells of the class (sum of q_len * t_len)
@@ -66,11 +68,14 @@ struct MyersState {
     bool perm_on_host = false;
     std::vector<MyersClass> classes;
     MyersBucket buckets[5];
-    double cells = 0;
+    double cells = 0;            // forward cells of the pairs that run
+    double cells_skipped = 0;    // cells of the pairs answered at stage time (query more than k longer than the target)
+    int64_t n_skipped = 0;       // their number; they are the last pairs of the sorted order
+    int32_t n_run = 0;           // pairs in front of them
     float ms[5] = {0, 0, 0, 0, 0};
     int64_t total_loc = 0, total_hit = 0;
     DevBuf seq, rseq, qoff, qlen, toff, tlen, k, ed, nloc, slots, packed, scanned, blocksum, locoff, hitoff,
-        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2, startitems, startinfo;
+        locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2, startitems, startinfo, hbuf;
     // staging: raw bytes, byte -> code table (+ presence mask), the pairs as the caller ordered them, sort scratch,
     // sorted position -> caller's index and its inverse, per-class statistics, unsorted work items
     DevBuf raw, lut, u_qoff, u_qlen, u_toff, u_tlen, u_k, skeys, perm_d, inv_d, stats, worktmp;

@@ -56,8 +56,11 @@ struct MyArgs {
     int32_t bstride, boff; // myers_mega: workgroup x of this launch takes work item x * bstride + boff (a bucket's list dealt over two launches)
     // start pass: the work items of a launch follow from the location range of each size class, so they are
     // computed from blockIdx (heaviest class first) instead of being listed by the host
-    struct { int32_t cls, first_block; int64_t b, e; } rr[4];
+    struct { int32_t cls, first_block; int64_t b, e; } rr[5];
     int32_t n_rr;
+    // long class (queries beyond 32768 rows, strips of 32768): two byte-per-column buffers per item for the horizontal
+    // deltas that leave one strip and enter the next; item `base` of a launch uses buffer pair base - hbase
+    uint8_t *hbuf; int64_t hstride, hbase;
     int32_t nbb;    // lane-group traceback: 64-row blocks stored per column (the ones the path's band crosses); 0 = all
     const int32_t *rev_items; // start pass over a list of locations (what the banded start kernels left), or nullptr = the range itself
 };
@@ -514,11 +517,15 @@ __global__ void __launch_bounds__(256) myers_lane(MyArgs a)
 // lane-group kernel: G lanes per pair, W words per lane, skewed (anti-diagonal) schedule
 // ------------------------------------------------------------------------------------------------
 // One wavefront's worth of work: items [base, base + 64/G).  slot0: first trace slot of the wavefront (MODE_NW).
-template <int G, int W, int MODE>
+// LONG (G = 64, W = 8 only): a query of any length, taken in strips of 32768 rows by the one wavefront.  A strip runs
+// over all columns; the horizontal deltas that leave its last row go to a byte-per-column buffer in HBM and enter the
+// next strip's first row (two buffers, alternating).  Only the last strip scores.  The top padding lies in strip 0.
+template <int G, int W, int MODE, bool LONG = false>
 __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64_t *lds_wave, int64_t slot0)
 {
+    static_assert(!LONG || (G == 64 && W == 8), "the long class is the widest wavefront-per-pair class, looped");
     constexpr int P = 64 / G;    // pairs per wave
-    constexpr int NB = G * W;    // words per pair
+    constexpr int NB = G * W;    // words per pair (and strip)
     constexpr int ROWS = 64 * NB;
     const int lane = threadIdx.x & 63;
     const int g = lane % G, p = lane / G;
@@ -529,21 +536,11 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         if (MODE == MODE_FWD_EXACT || MODE == MODE_NW) {
             if (!__any(it.valid)) return;
         }
-        const int pad = ROWS - it.m;
+        const int nstrip = LONG ? __builtin_amdgcn_readfirstlane((it.m + ROWS - 1) / ROWS) : 1;
+        const int NBT = NB * nstrip;          // blocks of the whole (padded) query
+        const int pad = ROWS * nstrip - it.m; // < ROWS
         const uint64_t padfill_on = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? ~(uint64_t)0 : 0;
         uint64_t Pv[W], Mv[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            const int blk = g * W + w;
-            for (int s = 0; s < S; s++) peq[s * NB + blk] = pad_mask(pad, blk) & padfill_on;
-            if (it.valid) {
-                for (int bit = 0; bit < 64; bit++) {
-                    int i = 64 * blk + bit - pad;
-                    if (i >= 0 && i < it.m) peq[(int)it.q[i] * NB + blk] |= ((uint64_t)1) << bit;
-                }
-            }
-            Pv[w] = ~pad_mask(pad, blk); Mv[w] = 0;
-        }
         const uint32_t top_hp = (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) ? 0u : 1u;
         int32_t score = it.m;
         int32_t best = 0x3fffffff, cnt = 0, lim = it.k, last = -1;
@@ -553,8 +550,8 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         ulonglong2 *tT = nullptr;
         if (MODE == MODE_NW) tT = a.tr + (slot0 + p) * a.region;
         // NW pass with a known distance: only the blocks that the ed + 1 reachable diagonals cross are stored
-        // (myers_band explains the range); nbb == NB stores everything.
-        const int nbb = (MODE == MODE_NW && a.nbb > 0 && a.nbb < NB) ? a.nbb : NB;
+        // (myers_band explains the range); nbb == NBT stores everything.
+        const int nbb = (MODE == MODE_NW && a.nbb > 0 && a.nbb < NBT) ? a.nbb : NBT;
         int lo_pad = 0;
         if (MODE == MODE_NW) {
             const int delta = it.m - it.n;
@@ -564,6 +561,30 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         const int n = it.valid ? it.n : 0;
         const int nmax = wave_max_i32(n);
         const int steps = nmax + G - 1;
+        uint8_t *hb0 = nullptr, *hb1 = nullptr; // LONG: 64 readable bytes in front of each, 16 behind column n
+        if (LONG) {
+            const int64_t hi = MODE == MODE_NW ? slot0 : base - a.hbase;
+            hb0 = a.hbuf + (2 * hi) * a.hstride + 64;
+            hb1 = hb0 + a.hstride;
+        }
+      for (int strip = 0; strip < nstrip; strip++) {
+        const bool last_strip = strip == nstrip - 1;
+        const uint8_t *hin = (strip & 1) ? hb0 : hb1; // what the strip before left
+        uint8_t *hout = (strip & 1) ? hb1 : hb0;
+        if (LONG && strip > 0) __threadfence();       // the strip before wrote hin through other lanes
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const int blk = g * W + w, gblk = strip * NB + blk;
+            for (int s = 0; s < S; s++) peq[s * NB + blk] = pad_mask(pad, gblk) & padfill_on;
+            if (it.valid) {
+                for (int bit = 0; bit < 64; bit++) {
+                    int i = 64 * gblk + bit - pad;
+                    if (i >= 0 && i < it.m) peq[(int)it.q[i] * NB + blk] |= ((uint64_t)1) << bit;
+                }
+            }
+            Pv[w] = ~pad_mask(pad, gblk); Mv[w] = 0;
+        }
+        score = it.m;
         uint32_t h_out = 0; // bit 0: +1 carry out of this lane's last word, bit 1: -1 carry
         if (MODE != MODE_NW) {
             // Forward / start passes.  Three things keep the per-step overhead down:
@@ -576,14 +597,17 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
             const int act_n = it.valid ? n : nmax;
             const int nmin = -wave_max_i32(-act_n);
             const uint8_t *tp = it.valid ? it.t : a.seq + 64; // 64 readable bytes lie in front of every target
-            int32_t limv = lastlane ? lim : (int32_t)0x80000000;
-            const int32_t revbest = lastlane ? it.best : (int32_t)0x80000000;
+            int32_t limv = (lastlane && last_strip) ? lim : (int32_t)0x80000000;
+            const int32_t revbest = (lastlane && last_strip) ? it.best : (int32_t)0x80000000;
             uint64_t tw = 0, twn = load8(tp - g);
+            uint64_t hw = 0, hwn = 0; // LONG: the deltas entering lane 0's first row, eight columns at a time like the target
+            if (LONG && strip > 0) hwn = load8(hin - g);
             auto step = [&](int t, auto tested) {
                 constexpr bool TESTED = decltype(tested)::value;
                 uint32_t h_in = G <= 16 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x111 /* row_shr:1 */, 0xf, 0xf, false)
                                         : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 if (g == 0) h_in = top_hp;
+                if (LONG && strip > 0) { if (g == 0) h_in = (uint32_t)(hw & 0xff); hw >>= 8; }
                 uint32_t hp = h_in & 1u, hm = h_in >> 1;
                 const int col = t - g;
                 const int code = (int)(tw & 0xff);
@@ -596,6 +620,7 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                         word_step(Pv[w], Mv[w], pe[w], hp, hm, ph0);
                     }
                     h_out = hp | (hm << 1);
+                    if (LONG && !last_strip && lastlane) hout[col] = (uint8_t)h_out;
                     score += (int32_t)hp - (int32_t)hm;
                     if (MODE == MODE_FWD || MODE == MODE_FWD_EXACT) {
                         if (score <= limv) {
@@ -614,6 +639,7 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                 int pos = tt - g + 8;
                 pos = pos < act_n ? pos : act_n;
                 twn = load8(tp + pos);
+                if (LONG && strip > 0) { hw = hwn; hwn = load8(hin + pos); }
             };
             const int t_fast0 = G - 1, t_fast1 = nmin > G - 1 ? nmin : G - 1;
             for (; t < t_fast0 && t < steps; t++) { if ((t & 7) == 0) refill(t); step(t, std::true_type{}); }
@@ -622,15 +648,21 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
         } else {
         uint64_t tw = 0;    // this lane's next target bytes (its column lags g steps behind lane 0)
         uint64_t twn = n > 0 ? load8(it.t) : 0; // the chunk after it, loaded eight columns ahead of its use
+        uint64_t hw = 0;    // LONG: the deltas entering lane 0's first row
         for (int t = 0; t < steps; t++) {
             // the carry moves one lane down per step: a DPP shift (inside a 16-lane row, or across the whole wavefront)
             uint32_t h_in = G <= 16 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x111 /* row_shr:1 */, 0xf, 0xf, false)
                                     : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             if (g == 0) h_in = top_hp;
-            uint32_t hp = h_in & 1u, hm = h_in >> 1;
             const int col = t - g;
             if (col >= 0 && col < n) {
                 if ((col & 7) == 0) { tw = twn; if (col + 8 < n) twn = load8(it.t + col + 8); }
+                if (LONG && strip > 0) {
+                    if ((col & 7) == 0) hw = load8(hin + col);
+                    if (g == 0) h_in = (uint32_t)(hw & 0xff);
+                    hw >>= 8;
+                }
+                uint32_t hp = h_in & 1u, hm = h_in >> 1;
                 const int code = (int)(tw & 0xff);
                 tw >>= 8;
                 const uint64_t *pe = peq + (size_t)code * NB + g * W;
@@ -640,14 +672,16 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                     word_step(Pv[w], Mv[w], pe[w], hp, hm, ph0);
                     ulonglong2 e; e.x = Pv[w]; e.y = ph0;
                     int f = (col + lo_pad) >> 6;
-                    f = f < 0 ? 0 : f > NB - nbb ? NB - nbb : f;
-                    const int rel = g * W + w - f;
+                    f = f < 0 ? 0 : f > NBT - nbb ? NBT - nbb : f;
+                    const int rel = strip * NB + g * W + w - f;
                     if (rel >= 0 && rel < nbb) tT[(int64_t)col * nbb + rel] = e;
                 }
                 h_out = hp | (hm << 1);
+                if (LONG && !last_strip && g == G - 1) hout[col] = (uint8_t)h_out;
             }
         }
         }
+      } // strips
         if (MODE == MODE_FWD) {
             if (it.valid && g == G - 1) { a.ed[it.pair] = (cnt > 0) ? best : -1; a.nloc[it.pair] = cnt; }
             const bool over = __any(it.valid && g == G - 1 && cnt > out_cap);
@@ -661,7 +695,7 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
                 if (a.ops && it.valid) { ops = a.ops + a.ops_off[it.pair]; ops_cap = (int)(a.ops_off[it.pair + 1] - a.ops_off[it.pair]); }
                 int ins = 0, nops = 0;
                 constexpr int TILE = 16 * (G < 8 ? G : 8); // entries of a pair's tile: P * TILE <= 1024 = the staging area
-                traceback_group<G>(tT, nbb, lo_pad, pad, ROWS, it.n, it.valid, it.q, it.t, ops, ops_cap, ins, nops,
+                traceback_group<G>(tT, nbb, lo_pad, pad, ROWS * nstrip, it.n, it.valid, it.q, it.t, ops, ops_cap, ins, nops,
                                    (ulonglong2 *)(lds_wave + (size_t)S * NB * P) + (size_t)p * TILE, lane, g);
                 if (it.valid && g == 0) {
                     a.first_ins[it.pair] = ins;
@@ -673,14 +707,14 @@ __device__ __forceinline__ void group_item(const MyArgs &a, int64_t base, uint64
     }
 }
 
-template <int G, int W, int MODE>
+template <int G, int W, int MODE, bool LONG = false>
 __global__ void __launch_bounds__(64) myers_group(MyArgs a)
 {
     if (MODE == MODE_NW) __builtin_amdgcn_s_setprio(3); // few, long wavefronts beside the band kernels (see myers_band)
     extern __shared__ uint64_t lds[];
     constexpr int P = 64 / G;
     for (int64_t base = a.begin + (int64_t)blockIdx.x * P; base < a.end; base += (int64_t)gridDim.x * P)
-        group_item<G, W, MODE>(a, base, lds, (int64_t)blockIdx.x * P);
+        group_item<G, W, MODE, LONG>(a, base, lds, (int64_t)blockIdx.x * P);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -704,7 +738,7 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
         int32_t cls = a.rr[0].cls, first = a.rr[0].first_block;
         int64_t rb = a.rr[0].b, re = a.rr[0].e;
 #pragma unroll
-        for (int t = 1; t < 4; t++)
+        for (int t = 1; t < 5; t++)
             if (t < a.n_rr && item >= a.rr[t].first_block) { cls = a.rr[t].cls; first = a.rr[t].first_block; rb = a.rr[t].b; re = a.rr[t].e; }
         wi.cls = cls;
         const int per = wi.cls < 4 ? 64 : wi.cls < 6 ? 32 : wi.cls < 8 ? 16 : wi.cls < 10 ? 8 : 1; // 64 / G of the class
@@ -734,7 +768,8 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
         case 10: group_item<64, 1, MODE>(a, wi.base, lds, 0); break;
         case 11: group_item<64, 2, MODE>(a, wi.base, lds, 0); break;
         case 12: group_item<64, 4, MODE>(a, wi.base, lds, 0); break;
-        default: group_item<64, 8, MODE>(a, wi.base, lds, 0); break;
+        case 13: group_item<64, 8, MODE>(a, wi.base, lds, 0); break;
+        default: group_item<64, 8, MODE, true>(a, wi.base, lds, 0); break;
         }
     }
 }
@@ -1581,12 +1616,14 @@ __global__ void __launch_bounds__(256) k_start_keys(MyArgs a, int64_t n_loc, uin
 // class are keyed by the size class of their query instead: each full-height kernel then gets a dense list of
 // exactly its hits.  (kBandLBits / kFullLBits: key layout of the banded start pass, k_start_keys.)
 constexpr uint32_t kBandLBits = 24, kFullLBits = 20;
-constexpr int kNumSizeClasses = 14;
+constexpr int kNumSizeClasses = 15; // 14 = the long class: wavefront per pair, strips of 32768 rows
+constexpr uint32_t kSkipClass = 15;  // sort key of the pairs answered without a launch (k_pair_keys)
+constexpr int kLongClass = 14;
 constexpr int kBandBounds = kBandClasses + kNumSizeClasses + 1; // first sorted position of each group, then the end
 __device__ __forceinline__ uint32_t size_class_of(int m)
 {
     return m <= 256 ? (uint32_t)((m - 1) >> 6) : m <= 384 ? 4u : m <= 512 ? 5u : m <= 768 ? 6u : m <= 1024 ? 7u : m <= 1536 ? 8u
-         : m <= 2048 ? 9u : m <= 4096 ? 10u : m <= 8192 ? 11u : m <= 16384 ? 12u : 13u;
+         : m <= 2048 ? 9u : m <= 4096 ? 10u : m <= 8192 ? 11u : m <= 16384 ? 12u : m <= 32768 ? 13u : 14u;
 }
 // Traceback routing keys, 14 bits (two radix passes instead of the four a 28-bit key with the exact length took):
 // band class (by distance), then a bin of the first location's length, longest first - exact below 256 columns,
@@ -1792,10 +1829,10 @@ const ClassDef kClasses[] = {
     {1, 1}, {1, 2}, {1, 3}, {1, 4},                   // <= 256 rows: lane per pair
     {2, 3}, {2, 4}, {4, 3}, {4, 4}, {8, 3}, {8, 4},   // 384, 512, 768, 1024, 1536, 2048 rows: 2..8 lanes per pair
     {64, 1}, {64, 2}, {64, 4}, {64, 8},               // 4096 .. 32768 rows: wavefront per pair
+    {64, 8},                                          // beyond: the same, in strips of 32768 rows (group_item<.., LONG>)
 };
 static_assert(sizeof(kClasses) / sizeof(kClasses[0]) == kNumSizeClasses, "size_class_of() and kClasses must agree");
-constexpr int kNumClasses = sizeof(kClasses) / sizeof(kClasses[0]);
-constexpr int kMaxQuery = 64 * 64 * 8;
+constexpr int kStripRows = 64 * 64 * 8;
 
 template <int W, int MODE> hipError_t launch_lane(hipStream_t stream, const MyArgs &a, int64_t items, int max_waves)
 {
@@ -1815,18 +1852,18 @@ template <int W, int MODE> hipError_t launch_lane(hipStream_t stream, const MyAr
     return hipGetLastError();
 }
 
-template <int G, int W, int MODE> hipError_t launch_group(hipStream_t stream, const MyArgs &a, int64_t items, int max_blocks)
+template <int G, int W, int MODE, bool LONG = false> hipError_t launch_group(hipStream_t stream, const MyArgs &a, int64_t items, int max_blocks)
 {
     constexpr int P = 64 / G;
     size_t shmem = (size_t)P * a.S * G * W * sizeof(uint64_t) + (MODE == MODE_NW ? (size_t)kStage * 2 * 64 * sizeof(ulonglong2) : 0);
     if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)myers_group<G, W, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipError_t e = hipFuncSetAttribute((const void *)myers_group<G, W, MODE, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
     int64_t blocks = (items + P - 1) / P;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL((myers_group<G, W, MODE>), dim3((unsigned)blocks), dim3(64), shmem, stream, a);
+    hipLaunchKernelGGL((myers_group<G, W, MODE, LONG>), dim3((unsigned)blocks), dim3(64), shmem, stream, a);
     return hipGetLastError();
 }
 
@@ -1847,12 +1884,13 @@ template <int MODE> hipError_t launch_class(hipStream_t ctx, int cls, const MyAr
     case 11: return launch_group<64, 2, MODE>(ctx, a, items, max_par);
     case 12: return launch_group<64, 4, MODE>(ctx, a, items, max_par);
     case 13: return launch_group<64, 8, MODE>(ctx, a, items, max_par);
+    case 14: return launch_group<64, 8, MODE, true>(ctx, a, items, max_par);
     }
     return hipErrorInvalidValue;
 }
 
 constexpr int kBuckets = 5;
-inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 10 ? 3 : 4; }
+inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 10 ? 3 : 4; } // the long class rides in bucket 4
 inline int bucket_wmax(int b) { return b == 0 ? 2 : b < 4 ? 4 : 8; } // words per lane: LDS per wavefront = S * wmax * 512 B
 
 // part / parts: this launch takes every parts-th work item of the list starting with item `part`, on lane `lane_i`
@@ -1881,13 +1919,6 @@ template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket,
     default: hipLaunchKernelGGL((myers_mega<MODE, 4>), dim3((unsigned)blocks), dim3(64), shmem, cs, a, d_list, n); break;
     }
     return hipGetLastError();
-}
-
-int class_of(int m)
-{
-    for (int c = 0; c < kNumClasses; c++)
-        if (m <= 64 * kClasses[c].G * kClasses[c].W) return c;
-    return -1;
 }
 
 } // namespace
@@ -2014,7 +2045,7 @@ void ultra_myers_free(ultra_ctx *ctx)
                       &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
                       &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff,
                       &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp, &st.trace2, &st.startitems, &st.startinfo,
-                      &st.raw, &st.lut, &st.u_qoff, &st.u_qlen, &st.u_toff, &st.u_tlen, &st.u_k, &st.skeys, &st.perm_d, &st.inv_d, &st.stats, &st.worktmp};
+                      &st.hbuf, &st.raw, &st.lut, &st.u_qoff, &st.u_qlen, &st.u_toff, &st.u_tlen, &st.u_k, &st.skeys, &st.perm_d, &st.inv_d, &st.stats, &st.worktmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto &bk : st.buckets) {
@@ -2062,36 +2093,50 @@ __global__ void __launch_bounds__(256) k_encode(const uint8_t *raw, int64_t n, c
     }
 }
 
-// stats: [0..14) pairs per size class, [14..28) forward cells per class, [28..42) longest target per class
-__global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const int32_t *t_len, int32_t n, uint32_t *keys, int32_t *idx,
-                                                   unsigned long long *stats)
+// A pair whose query is more than k bases longer than its target cannot be a hit: in HW mode every alignment of the
+// whole query leaves at least m - n query bases unmatched, so the distance is at least m - n > k and edlib answers -1
+// (it gives up within a few columns: its band never reaches the last row).  With the reference's k = 0.4 * min(m, n)
+// (classify_read_with_mams.py:312) that is every flank and exon segment longer than 1.4 x the read - the tallest,
+// slowest size classes.  They sort behind every class and get their answer at stage time; no launch sees them.
+__device__ __forceinline__ bool pair_cannot_hit(int m, int t, int k)
 {
-    __shared__ unsigned long long sh[3 * kNumSizeClasses];
-    for (int i = threadIdx.x; i < 3 * kNumSizeClasses; i += blockDim.x) sh[i] = 0;
+    const int ke = (k < 0 || k > m) ? m : k; // as setup_item clamps it
+    return m - t > ke;
+}
+// stats, kStatN = 16 entries each: pairs per size class ([15] = skipped), forward cells per class ([15] = the cells the
+// skipped pairs would have cost), longest target per class, longest query per class
+constexpr int kStatN = 16;
+__global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const int32_t *t_len, const int32_t *k, int32_t n, uint32_t *keys,
+                                                   int32_t *idx, unsigned long long *stats)
+{
+    __shared__ unsigned long long sh[4 * kStatN];
+    for (int i = threadIdx.x; i < 4 * kStatN; i += blockDim.x) sh[i] = 0;
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) {
         const int m = q_len[p], t = t_len[p];
-        const uint32_t c = size_class_of(m);
+        const uint32_t c = pair_cannot_hit(m, t, k[p]) ? kSkipClass : size_class_of(m);
         // Lane classes (m <= 256): queries that leave the lower half of their first word empty sort together, so that
         // whole wavefronts can run that word on one 32-bit half (lane_forward).
         const uint32_t half = (c < 4 && ((c + 1) * 64 - (uint32_t)m) >= 32) ? 1u : 0u;
         keys[p] = (c << 25) | (half << 24) | (uint32_t)(t < 0xFFFFFF ? t : 0xFFFFFF);
         idx[p] = p;
         atomicAdd(&sh[c], 1ull);
-        atomicAdd(&sh[kNumSizeClasses + c], (unsigned long long)m * (unsigned long long)t);
-        atomicMax(&sh[2 * kNumSizeClasses + c], (unsigned long long)t);
+        atomicAdd(&sh[kStatN + c], (unsigned long long)m * (unsigned long long)t);
+        atomicMax(&sh[2 * kStatN + c], (unsigned long long)t);
+        atomicMax(&sh[3 * kStatN + c], (unsigned long long)m);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * kNumSizeClasses; i += blockDim.x) {
+    for (int i = threadIdx.x; i < 4 * kStatN; i += blockDim.x) {
         if (!sh[i]) continue;
-        if (i < 2 * kNumSizeClasses) atomicAdd(&stats[i], sh[i]); else atomicMax(&stats[i], sh[i]);
+        if (i < 2 * kStatN) atomicAdd(&stats[i], sh[i]); else atomicMax(&stats[i], sh[i]);
     }
 }
 
 __global__ void __launch_bounds__(256) k_gather_pairs(const int32_t *perm, int32_t n, int64_t shift,
                                                       const int64_t *uq, const int32_t *uql, const int64_t *ut, const int32_t *utl, const int32_t *uk,
-                                                      int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k, int32_t *inv)
+                                                      int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k, int32_t *inv,
+                                                      int32_t *ed, int32_t *nloc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2099,10 +2144,12 @@ __global__ void __launch_bounds__(256) k_gather_pairs(const int32_t *perm, int32
     q_off[i] = uq[p] + shift; t_off[i] = ut[p] + shift;
     q_len[i] = uql[p]; t_len[i] = utl[p]; k[i] = uk[p];
     inv[p] = i;
+    // the pairs no launch takes (pair_cannot_hit) are answered here; every run of the staged batch leaves them alone
+    if (pair_cannot_hit(uql[p], utl[p], uk[p])) { ed[i] = -1; nloc[i] = 0; }
 }
 
-struct WorkRanges { int32_t n; struct { int32_t cls, G, W, first_item; int64_t pb, pe; } r[4]; };
-__global__ void __launch_bounds__(256) k_work_items(WorkRanges wr, const int32_t *t_len, int32_t n_items, WorkItem *items, uint32_t *keys, int32_t *idx)
+struct WorkRanges { int32_t n; struct { int32_t cls, G, W, first_item; int64_t pb, pe; } r[5]; };
+__global__ void __launch_bounds__(256) k_work_items(WorkRanges wr, const int32_t *q_len, const int32_t *t_len, int32_t n_items, WorkItem *items, uint32_t *keys, int32_t *idx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
@@ -2114,7 +2161,8 @@ __global__ void __launch_bounds__(256) k_work_items(WorkRanges wr, const int32_t
     wi.end = wr.r[r].pe;
     wi.cls = wr.r[r].cls;
     const int64_t last = (wi.base + per < wi.end ? wi.base + per : wi.end) - 1;
-    const int64_t cost = (int64_t)wr.r[r].W * ((int64_t)t_len[last] + wr.r[r].G); // ~ words per lane x columns
+    int64_t cost = (int64_t)wr.r[r].W * ((int64_t)t_len[last] + wr.r[r].G); // ~ words per lane x columns
+    if (wr.r[r].cls == kLongClass) cost *= (q_len[last] + kStripRows - 1) / kStripRows; // one pair per item, strip after strip
     wi.cost = (int32_t)(cost < 0x7fffffff ? cost : 0x7fffffff);
     items[i] = wi;
     keys[i] = (uint32_t)wi.cost;
@@ -2150,7 +2198,7 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
     st.n_pairs = n_pairs;
     st.perm.clear(); st.perm_on_host = false;
     st.classes.clear();
-    st.cells = 0;
+    st.cells = 0; st.cells_skipped = 0; st.n_skipped = 0;
     const size_t np = (size_t)std::max(n_pairs, 1);
     ULTRA_HIP_CHECK(ctx, st.qoff.ensure(np * 8)); ULTRA_HIP_CHECK(ctx, st.toff.ensure(np * 8));
     ULTRA_HIP_CHECK(ctx, st.qlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.tlen.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.k.ensure(np * 4));
@@ -2163,7 +2211,7 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
     ULTRA_HIP_CHECK(ctx, st.bounds.ensure(64 * 8 * 4));
     ULTRA_HIP_CHECK(ctx, st.skeys.ensure(np * 4 * 4)); // keys in | keys out | index in | index out (pairs, then work items)
     ULTRA_HIP_CHECK(ctx, st.perm_d.ensure(np * 4)); ULTRA_HIP_CHECK(ctx, st.inv_d.ensure(np * 4));
-    ULTRA_HIP_CHECK(ctx, st.stats.ensure(3 * kNumSizeClasses * 8));
+    ULTRA_HIP_CHECK(ctx, st.stats.ensure(4 * kStatN * 8));
     for (auto &e : st.ev) if (!e) ULTRA_HIP_CHECK(ctx, hipEventCreate(&e));
     for (int b = 0; b < kBuckets; b++) {
         MyersBucket &bk = st.buckets[b];
@@ -2175,9 +2223,9 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
     uint32_t *k_in = st.skeys.as<uint32_t>(), *k_out = k_in + np;
     int32_t *i_in = (int32_t *)(k_out + np), *i_out = i_in + np;
     const unsigned gp = (unsigned)((n_pairs + 255) / 256);
-    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.stats.p, 0, 3 * kNumSizeClasses * 8, s));
-    hipLaunchKernelGGL(k_pair_keys, dim3(gp), dim3(256), 0, s, st.u_qlen.as<int32_t>(), st.u_tlen.as<int32_t>(), n_pairs, k_in, i_in,
-                       st.stats.as<unsigned long long>());
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.stats.p, 0, 4 * kStatN * 8, s));
+    hipLaunchKernelGGL(k_pair_keys, dim3(gp), dim3(256), 0, s, st.u_qlen.as<int32_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(), n_pairs,
+                       k_in, i_in, st.stats.as<unsigned long long>());
     {
         size_t tmp_bytes = 0;
         ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 29, s));
@@ -2187,32 +2235,36 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
     hipLaunchKernelGGL(k_gather_pairs, dim3(gp), dim3(256), 0, s, st.perm_d.as<int32_t>(), n_pairs, (int64_t)kArenaPad,
                        st.u_qoff.as<int64_t>(), st.u_qlen.as<int32_t>(), st.u_toff.as<int64_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(),
                        st.qoff.as<int64_t>(), st.qlen.as<int32_t>(), st.toff.as<int64_t>(), st.tlen.as<int32_t>(), st.k.as<int32_t>(),
-                       st.inv_d.as<int32_t>());
+                       st.inv_d.as<int32_t>(), st.ed.as<int32_t>(), st.nloc.as<int32_t>());
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    unsigned long long h_stats[3 * kNumSizeClasses];
+    unsigned long long h_stats[4 * kStatN];
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_stats, st.stats.p, sizeof h_stats, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
     int64_t at = 0;
     for (int c = 0; c < kNumSizeClasses; c++) {
         const int64_t cnt = (int64_t)h_stats[c];
         if (cnt <= 0) continue;
-        MyersClass mc; mc.G = kClasses[c].G; mc.W = kClasses[c].W; mc.pb = at; mc.pe = at + cnt;
-        mc.max_t = (int32_t)h_stats[2 * kNumSizeClasses + c];
+        MyersClass mc; mc.cls = c; mc.G = kClasses[c].G; mc.W = kClasses[c].W; mc.pb = at; mc.pe = at + cnt;
+        mc.max_t = (int32_t)h_stats[2 * kStatN + c];
+        mc.max_m = (int32_t)h_stats[3 * kStatN + c];
         mc.lb = mc.le = mc.hb = mc.he = 0;
-        mc.cells = (double)h_stats[kNumSizeClasses + c];
+        mc.cells = (double)h_stats[kStatN + c];
         st.classes.push_back(mc);
         st.cells += mc.cells;
         st.buckets[bucket_of(c)].cells += mc.cells;
         at += cnt;
     }
-    if (at != n_pairs) return ultra_fail(ctx, ULTRA_E_HIP, "ultra_myers_stage: size-class counts do not add up");
+    st.n_skipped = (int64_t)h_stats[kSkipClass];
+    st.cells_skipped = (double)h_stats[kStatN + kSkipClass];
+    st.n_run = (int32_t)at; // the skipped pairs lie behind every class
+    if (at + st.n_skipped != n_pairs) return ultra_fail(ctx, ULTRA_E_HIP, "ultra_myers_stage: size-class counts do not add up");
     // forward work lists (heaviest wavefront first), one per register bucket
     for (int b = 0; b < kBuckets; b++) {
         MyersBucket &bk = st.buckets[b];
         WorkRanges wr; wr.n = 0;
         int32_t n_items = 0;
         for (auto &mc : st.classes) {
-            const int cls = class_of(64 * mc.G * mc.W);
+            const int cls = mc.cls;
             if (bucket_of(cls) != b) continue;
             const int per = 64 / mc.G;
             wr.r[wr.n].cls = cls; wr.r[wr.n].G = mc.G; wr.r[wr.n].W = mc.W; wr.r[wr.n].first_item = n_items;
@@ -2226,7 +2278,7 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
         ULTRA_HIP_CHECK(ctx, bk.fwd_flag.ensure((size_t)n_items * sizeof(int32_t)));
         ULTRA_HIP_CHECK(ctx, st.worktmp.ensure((size_t)n_items * sizeof(WorkItem)));
         const unsigned gi = (unsigned)((n_items + 255) / 256);
-        hipLaunchKernelGGL(k_work_items, dim3(gi), dim3(256), 0, s, wr, st.tlen.as<int32_t>(), n_items, st.worktmp.as<WorkItem>(), k_in, i_in);
+        hipLaunchKernelGGL(k_work_items, dim3(gi), dim3(256), 0, s, wr, st.qlen.as<int32_t>(), st.tlen.as<int32_t>(), n_items, st.worktmp.as<WorkItem>(), k_in, i_in);
         size_t tmp_bytes = 0;
         ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)n_items, 0, 32, s));
         ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
@@ -2269,9 +2321,6 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
             (uint64_t)q_off[p] + (uint64_t)q_len[p] > arena_len || (uint64_t)t_off[p] + (uint64_t)t_len[p] > arena_len)
             return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_stage: pair " + std::to_string(p) +
                                                     " has an empty sequence or offsets outside the arena");
-        if (class_of(q_len[p]) < 0)
-            return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_stage: query of pair " + std::to_string(p) + " is longer than " +
-                                                            std::to_string(kMaxQuery) + " bases");
     }
     hipStream_t s = ctx->stream;
     ultra_drain_guard drain(ctx);
@@ -2370,6 +2419,23 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     a.loc_off = st.locoff.as<int64_t>(); a.hit_pairs = st.hitpairs.as<int32_t>(); a.first_ins = st.firstins.as<int32_t>();
     a.n_ops = st.nops.as<int32_t>();
 
+    // long class: the strips' hand-over buffers, two per item of a pass (pairs now, locations and hits later)
+    const MyersClass *longc = nullptr;
+    for (auto &mc : st.classes) if (mc.cls == kLongClass) longc = &mc;
+    const int64_t hstride = longc ? (((int64_t)longc->max_t + 64 + 16 + 63) & ~(int64_t)63) : 0;
+    auto long_buffers = [&](int64_t items) -> int {
+        const uint64_t bytes = (uint64_t)2 * (uint64_t)std::max<int64_t>(items, 1) * (uint64_t)hstride;
+        if (bytes > ((uint64_t)4 << 30))
+            return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_run: more than 4 GiB of strip buffers for queries beyond 32768 bases");
+        ULTRA_HIP_CHECK(ctx, st.hbuf.ensure((size_t)bytes + 64));
+        a.hbuf = st.hbuf.as<uint8_t>(); a.hstride = hstride;
+        return ULTRA_OK;
+    };
+    if (longc) {
+        const int lrc = long_buffers(longc->pe - longc->pb);
+        if (lrc != ULTRA_OK) return lrc;
+        a.hbase = longc->pb;
+    }
     ultra_drain_guard drain(ctx); // any early return below first waits for what has been enqueued
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.firstins.p, 0, (size_t)n * 4, s));
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.nops.p, 0, (size_t)n * 4, s));
@@ -2403,7 +2469,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         BucketFirst bf;
         for (int b = 0; b <= kBuckets; b++) bf.first[b] = n;
         for (auto mc = st.classes.rbegin(); mc != st.classes.rend(); ++mc) {
-            const int b = bucket_of(class_of(64 * mc->G * mc->W));
+            const int b = bucket_of(mc->cls);
             for (int t = 0; t <= b; t++) bf.first[t] = std::min<int32_t>(bf.first[t], (int32_t)mc->pb);
         }
         bf.first[0] = 0;
@@ -2456,6 +2522,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     a.loc_end = st.locend.as<int32_t>(); a.loc_start = st.locstart.as<int32_t>(); a.loc_pair = st.locpair.as<int32_t>();
+    if (longc && longc->le - longc->lb > longc->pe - longc->pb) { // more locations than pairs: the start pass needs more buffers
+        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        const int lrc = long_buffers(longc->le - longc->lb);
+        if (lrc != ULTRA_OK) return lrc;
+    }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare), and
     //      pass 2: start positions. ----
@@ -2472,8 +2543,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             ab.n_rr = 0;
             int32_t blocks = 0;
             for (auto mc = st.classes.rbegin(); mc != st.classes.rend(); ++mc) { // heaviest class of the bucket first
-                const int cls = class_of(64 * mc->G * mc->W);
+                const int cls = mc->cls;
                 if (bucket_of(cls) != b || mc->le <= mc->lb) continue;
+                if (cls == kLongClass) ab.hbase = mc->lb;
                 const int per = 64 / mc->G;
                 ab.rr[ab.n_rr].cls = cls; ab.rr[ab.n_rr].first_block = blocks; ab.rr[ab.n_rr].b = mc->lb; ab.rr[ab.n_rr].e = mc->le;
                 ab.n_rr++;
@@ -2527,6 +2599,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
                 const int per = 64 / kClasses[cls].G;
                 ab.rr[ab.n_rr].cls = cls; ab.rr[ab.n_rr].first_block = blocks; ab.rr[ab.n_rr].b = lb; ab.rr[ab.n_rr].e = le;
                 ab.n_rr++;
+                if (cls == kLongClass) ab.hbase = lb;
                 blocks += (int32_t)((le - lb + per - 1) / per);
             }
             st.buckets[b].n_rev = blocks;
@@ -2720,7 +2793,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         for (auto &mc : st.classes) {
             if (mc.he <= mc.hb) continue;
             FullPlan fp;
-            fp.cls = class_of(64 * mc.G * mc.W);
+            fp.cls = mc.cls;
             fp.begin = mc.hb; fp.end = mc.he;
             if (use_band) { fp.begin = full_first[fp.cls]; fp.end = full_first[fp.cls + 1]; } // dense list of what the banded kernels left
             fp.items = fp.end - fp.begin;
@@ -2729,9 +2802,10 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         }
         size_t total = 0;
         for (auto &fp : plans) {
-            const int G = kClasses[fp.cls].G, W = kClasses[fp.cls].W, NB = G * W;
-            int32_t max_t = 0;
-            for (auto &mc : st.classes) if (class_of(64 * mc.G * mc.W) == fp.cls) max_t = mc.max_t;
+            const int G = kClasses[fp.cls].G, W = kClasses[fp.cls].W;
+            int32_t max_t = 0, max_m = 0;
+            for (auto &mc : st.classes) if (mc.cls == fp.cls) { max_t = mc.max_t; max_m = mc.max_m; }
+            const int NB = fp.cls == kLongClass ? G * W * ((max_m + kStripRows - 1) / kStripRows) : G * W; // blocks of the tallest query
             // first location: L = end - start + 1 <= m + ed <= m + k, and k <= m (clamped in setup_item)
             fp.Lmax = std::min<int64_t>(max_t, (int64_t)2 * 64 * NB);
             const size_t share = budget / plans.size();

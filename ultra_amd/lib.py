@@ -20,7 +20,7 @@ _ERR_NAMES = {-1: "ULTRA_E_ARG", -2: "ULTRA_E_HIP", -3: "ULTRA_E_CAPACITY", -4: 
 EXPORTS = [
     "ultra_cfg_default", "ultra_ctx_create", "ultra_ctx_destroy", "ultra_last_error", "ultra_device_count",
     "ultra_device_info", "ultra_host_alloc", "ultra_host_free", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
-    "ultra_myers_last_timing", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
+    "ultra_myers_last_timing", "ultra_myers_cell_counts", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
     "ultra_chain_mams_batch_noalloc", "ultra_chain_noalloc_capacity",
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
     "ultra_index_create", "ultra_index_destroy", "ultra_plan_create", "ultra_plan_input", "ultra_plan_cands",
@@ -114,6 +114,7 @@ def load():
     lib.ultra_myers_run.argtypes = [vp]
     lib.ultra_myers_fetch.argtypes = [vp, i32p, i32p, i64p, i32p, i32p, C.c_int64, i64p, i32p]
     lib.ultra_myers_last_timing.argtypes = [vp, f64p, C.POINTER(C.c_float)]
+    lib.ultra_myers_cell_counts.argtypes = [vp, f64p, f64p, i64p]
     lib.ultra_myers_class_timing.argtypes = [vp, C.c_int32, i32p, i32p, f64p, C.POINTER(C.c_float), i32p]
     lib.ultra_chain_mams_batch.argtypes = [vp, C.c_int32, i64p, i32p, i32p, i32p, i32p, f64p, C.c_int32, C.c_int32,
                                            C.c_int32, i32p, i32p, f64p]
@@ -272,6 +273,13 @@ class Context(object):
         ms = (C.c_float * 5)()
         self._check(self.lib.ultra_myers_last_timing(self._h, C.byref(cells), ms))
         return cells.value, [ms[i] for i in range(5)]
+
+    def myers_cell_counts(self):
+        """Of the staged batch: (cells the forward pass computes, cells of the pairs answered at stage time because the
+        query is more than k longer than the target, number of those pairs)."""
+        a, b, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.ultra_myers_cell_counts(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def myers_class_timing(self):
         """{(G, W): (cells, forward_ms)} of the last run."""
