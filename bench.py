@@ -9,10 +9,12 @@ not exist offline): a GENCODE-shaped annotation of ~60 000 genes on 24 chromosom
 (ultra_amd/synth.py WORLDS["c3"]) and 1 000 000 DISTINCT simulated ONT-cDNA reads per GPU (7 % errors, N(1000, 400),
 the reference simulator's error mix) as 4 batches of 262 144, each with its NAM chain.
 
-A "step" is one pass of the hot path over one batch whose inputs are already resident in HBM: Myers forward / start /
-traceback kernels, MAM materialisation, chaining (ultra_mam_run).  The batches are planned on the device
-(ultra_mam_stage_nams over the resident index) into one context each before the timed region; the timed steps cycle
-through them, so no batch is replayed back to back.  Reads are independent: with N > 1 the job is N x 4 batches dealt
+A "step" is one pass of the WHOLE hot path over one batch whose inputs (the reads and their NAM chains, the packed
+index) are already resident in HBM: candidate enumeration on the device (ultra_mam_plan_resident: row a4 of SURVEY.md
+section 8 - classify_read_with_mams.py:180-300, :441-523), pair sort and work lists, then Myers forward / start /
+traceback kernels, MAM materialisation and chaining (ultra_mam_run).  Every batch is uploaded into a context of its
+own before the timed region (ultra_mam_upload_nams); the timed steps cycle through them, so no batch is replayed back
+to back.  `kernels_only` is the same without the enumeration (round 2's `value`).  Reads are independent: with N > 1 the job is N x 4 batches dealt
 round-robin over the ranks (ultra_amd/shard.py), weak scaling, no data-path collective; torch.distributed only
 provides the barrier and the max-over-ranks time.
 
@@ -96,10 +98,11 @@ def _cpu_worker(rng):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(idx, insts, min_acc, seconds, workers, cells_per_read):
+def cpu_baseline(idx, insts, min_acc, seconds, workers):
     import multiprocessing as mp
     from oracle import cport
     cport.lib()
+    cport.set_length_prefilter(1)   # as edlib's band and the GPU path: no cells for queries more than k longer than the target
     _CPU.update(idx=idx, insts=insts, min_acc=min_acc)
     n_cal = min(24, len(insts))
     per = _cpu_worker(range(n_cal)) / n_cal                     # calibrate, then size both samples to `seconds`
@@ -113,11 +116,10 @@ def cpu_baseline(idx, insts, min_acc, seconds, workers, cells_per_read):
     wall = time.perf_counter() - t0
     return {"value": n / wall, "unit": "reads/s", "cores": workers, "kind": "port",
             "sample": "%d reads of batch 0 through oracle/classify_port.py + liboracle.so (C Myers bit-vector without an "
-                      "Ukkonen band + chainers), %d fork workers (pool capped at the box's CPU share of %d; %d cores "
+                      "Ukkonen band, pairs whose query is more than k longer than the target answered without a DP, + "
+                      "chainers), %d fork workers (pool capped at the box's CPU share of %d; %d cores "
                       "visible), %.1f s wall" % (n, workers, CPU_SHARE, len(os.sched_getaffinity(0)), wall),
-            "gcups": n * cells_per_read / wall * 1e-9,
-            "one_thread": {"value": n1 / t1, "unit": "reads/s", "cores": 1, "gcups": n1 * cells_per_read / t1 * 1e-9,
-                           "sample": "%d reads, %.1f s" % (n1, t1)},
+            "one_thread": {"value": n1 / t1, "unit": "reads/s", "cores": 1, "sample": "%d reads, %.1f s" % (n1, t1)},
             "reference_cli": "uLTRA align not present on the box (edlib, namfinder, minimap2 are not installable offline)"}
 
 
@@ -171,7 +173,9 @@ def main():
     world_s = time.perf_counter() - t0
     my_batches = shard.deal_batches(world * args.batches, rank, world, batch=1)     # batch ids of this rank
     t0 = time.perf_counter()
-    sets = [synth.make_reads_native(flat, args.reads, seed=1000 + b, preset=args.preset, threads=CPU_SHARE) for b in my_batches]
+    # the ranks of a node generate side by side: each takes its share of the cores that go with the node's GPUs
+    gen_threads = max(1, min(CPU_SHARE, len(os.sched_getaffinity(0)) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+    sets = [synth.make_reads_native(flat, args.reads, seed=1000 + b, preset=args.preset, threads=gen_threads) for b in my_batches]
     reads_s = time.perf_counter() - t0
     import torch  # noqa: F401  (before libultra_hip.so is loaded: both must end up on the same HIP runtime - torch's)
     t0 = time.perf_counter()
@@ -183,12 +187,7 @@ def main():
         workers = max(1, min(CPU_SHARE, len(os.sched_getaffinity(0))))
         n_sample = min(len(sets[0]), 4096)
         sample = [sets[0].instance(i) for i in range(n_sample)]
-        # forward cells per read of the sample, from the host planner (the figure the GPU side reports per batch)
-        s0 = sets[0].slice(0, n_sample)
-        pl = nix.plan_arrays(s0.nam_off, s0.nam_part.reshape(-1, 3), s0.nam_x, s0.nam_y, s0.reads, s0.read_off)
-        cells_per_read = pl.cells / float(n_sample)
-        pl.close()
-        cpu = cpu_baseline(idx, sample, P["min_acc"], args.cpu_seconds, workers, cells_per_read)
+        cpu = cpu_baseline(idx, sample, P["min_acc"], args.cpu_seconds, workers)
 
     # ---- GPU: bind the rank's device before anything else touches HIP ----
     import torch
@@ -231,6 +230,7 @@ def main():
 
     nb = len(ctxs)
     for i in range(args.warmup):
+        ctxs[i % nb].mam_plan_resident(dix)
         ctxs[i % nb].mam_run(P["min_acc"])
     # once more, staged a second time: what a batch costs to stage when the buffers exist already
     t0 = time.perf_counter()
@@ -239,14 +239,22 @@ def main():
     ctxs[0].mam_run(P["min_acc"])
     class_ms = {}
     acc = {"fwd": 0.0, "rev": 0.0, "tb": 0.0, "all": 0.0, "fwdk": 0.0, "build": 0.0, "chain": 0.0, "gather": 0.0}
-    cells_run = 0.0
+    cells_run = cells_skip = pairs_skip = 0.0
+    plan_s = run_s = 0.0
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         c = ctxs[i % nb]
+        t1 = time.perf_counter()
+        c.mam_plan_resident(dix)        # a4's enumeration, pair sort, work lists: from the request resident in HBM
+        t2 = time.perf_counter()
         c.mam_run(P["min_acc"])
+        run_s += time.perf_counter() - t2
+        plan_s += t2 - t1
         cells, ms = c.myers_timing()
         cells_run += cells
+        sk = c.myers_cell_counts()
+        cells_skip += sk[1]; pairs_skip += sk[2]
         acc["fwd"] += ms[0]; acc["rev"] += ms[1]; acc["tb"] += ms[2]; acc["all"] += ms[3]; acc["fwdk"] += ms[4]
         mm = c.mam_timing()
         acc["build"] += mm[0]; acc["chain"] += mm[1]; acc["gather"] += mm[2]
@@ -257,6 +265,7 @@ def main():
     elapsed = time.perf_counter() - t0
     K = args.steps
     elapsed, reads_all, cells_all = shard.reduce_job(elapsed, args.reads * K, cells_run, device=red_dev)
+    run_max, _, cells_skip_all = shard.reduce_job(run_s, 0, cells_skip, device=red_dev)
 
     # ---- results back to the host (PCIe; outside the timed region) + parity spot check against the oracle ----
     t1 = time.perf_counter()
@@ -337,7 +346,7 @@ def main():
                "output": "chains with kind / chromosome in pinned host memory", "per_batch_ms": ms_pin,
                "pageable_input": {"reads_per_s": rate_pg, "per_batch_ms": ms_pg},
                "chain_rows_fetched": chains,
-               "synchronous_caller_reads_per_s": args.reads / ((restage_ms + elapsed / K * 1e3 + fetch_s * 1e3) * 1e-3)}
+               "synchronous_caller_reads_per_s": args.reads / ((restage_ms + run_max / K * 1e3 + fetch_s * 1e3) * 1e-3)}
 
     micro = None
     if rank == 0 and args.micro:
@@ -348,7 +357,13 @@ def main():
         peak_ops = info["n_cu"] * LANES_PER_CU_CLK * PEAK_CLOCK_GHZ * 1e9
         n_pairs = float(np.mean([c[2] for c in counts]))
         n_cands = float(np.mean([c[1] for c in counts]))
-        cells_step = cells_all / world / K
+        cells_step = cells_all / world / K                 # cells the forward pass computes
+        cells_ref_step = cells_step + cells_skip_all / world / K   # sum of m * n over every edlib call of the reference
+        if cpu:
+            cpr = cells_step / args.reads
+            cpu["gcups"] = cpu["value"] * cpr * 1e-9
+            cpu["one_thread"]["gcups"] = cpu["one_thread"]["value"] * cpr * 1e-9
+            cpu["gcups_note"] = "reads/s x the batch's computed cells per read (%.3g)" % cpr
         dom = max(class_ms.items(), key=lambda kv: kv[1][1]) if class_ms else None
         roof = None
         if dom:
@@ -393,21 +408,31 @@ def main():
                             alg_bytes / (acc["all"] / K * 1e-3) * 1e-9 if alg_bytes and acc["all"] > 0 else None,
                             "peak_GBs": HBM_PEAK_GBS}}
         line = {
-            "metric": "reads aligned/sec (whole node), MAM stage: Myers HW matching + MAM chaining",
+            "metric": "reads aligned/sec (whole node), MAM stage: candidate enumeration + Myers HW matching + MAM chaining",
             "value": reads_all / elapsed, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 bit-vectors / int32 scores (Myers), f64 (chaining)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] synthetic form (SURVEY.md 8d C3): %d-gene / %d-chromosome GENCODE-shaped annotation with "
-                                   "overlapping genes (%d transcripts, %d segments), %d distinct %s reads per GPU (err %.2f, ~%d bp) as %d batches of %d, "
-                                   "device-resident, one step = one batch"
+                                   "overlapping genes (%d transcripts, %d segments), %d distinct %s reads per GPU (err %.2f, lengths drawn from the "
+                                   "preset's model and cut to the transcript: mean %d bp) as %d batches of %d, reads + NAM chains + index "
+                                   "resident in HBM, one step = enumeration + alignment + chaining of one batch"
                                    % (wkw["n_genes"], wkw["n_chr"], len(w.transcripts), len(w.ref_segment_sequences), args.reads * nb, args.preset,
                                       P["err"], int(np.mean([rs.reads.size / max(len(rs), 1) for rs in sets])), nb, args.reads),
                        "reads_per_gpu_per_step": args.reads, "distinct_batches_per_gpu": nb, "pairs_per_step_per_gpu": n_pairs,
                        "candidates_per_step_per_gpu": n_cands, "cells_per_step_per_gpu": cells_step, "cells_per_read": cells_step / args.reads,
+                       "cells_reference_per_step_per_gpu": cells_ref_step, "cells_computed_per_step_per_gpu": cells_step,
+                       "pairs_answered_by_length_per_step": pairs_skip / K,
+                       "cells_note": "cells_reference = sum of m * n over every edlib.align call the reference makes; cells_computed "
+                                     "leaves out the pairs whose query is more than k longer than the target (distance >= m - n > k: "
+                                     "edlib answers -1 without reaching the last row, the library at stage time); every GCUPS / "
+                                     "roofline figure is taken over cells_computed",
                        "hw_queues": HW_QUEUES, "parallelism": "batches dealt over %d rank(s), no collective" % world,
                        **({"rehearsal": "all ranks share GPU 0, gloo rendezvous: the path is exercised, the value is not a measurement"} if args.rehearse else {})},
             "myers_gcups_forward": cells_all / (acc["fwd"] * 1e-3) * 1e-9 / world if acc["fwd"] > 0 else None,
             "myers_gcups_all_passes": cells_all / (acc["all"] * 1e-3) * 1e-9 / world if acc["all"] > 0 else None,
+            "kernels_only": {"reads_per_s": reads_all / run_max, "ms_per_step": run_max / K * 1e3,
+                             "note": "ultra_mam_run alone (candidates and sorted pairs already staged): what round 2 reported as value"},
+            "plan_ms_per_step": plan_s / K * 1e3,
             "stage_ms_per_step": {"myers_forward": acc["fwd"] / K, "myers_starts": acc["rev"] / K, "myers_traceback": acc["tb"] / K,
                                   "myers_total": acc["all"] / K, "mam_build": acc["build"] / K, "chain": acc["chain"] / K,
                                   "chain_gather": acc["gather"] / K},

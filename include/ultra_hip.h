@@ -153,8 +153,9 @@ int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
                            int32_t *chain_idx, int32_t *chain_len, double *value);
 
 /*
- * ultra_chain_mams_batch for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under
- * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same results, bit for
+ * ultra_chain_mams_batch for callers that cannot allocate device memory.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * tight serving loops with a fixed memory budget and harnesses that forbid hipMalloc (the call itself is synchronous -
+ * host copies and a stream synchronisation - so it is not meant to be recorded into a HIP graph).  Same arguments, same results, bit for
  * bit, as ultra_chain_mams_batch above; but every byte of device memory it needs beyond the caller's host arrays
  * (staging copies of the MAM arrays, launch lists, result vectors, the n log n solver's tree arrays) lives in a fixed
  * 8 MiB array inside the library image - no hipMalloc / hipFree, no growable context buffers.
@@ -162,7 +163,8 @@ int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
  *     MAM of an instance that takes the n log n solver); beyond that the call returns ULTRA_E_CAPACITY and touches
  *     nothing - split the batch, or use ultra_chain_mams_batch;
  *   - every GPU the library runs on holds its own copy of the array until the process ends;
- *   - all calls on one GPU share that GPU's array (whatever the context): calls that overlap on one GPU race.
+ *   - all calls on one GPU share that GPU's array (whatever the context): the library serialises them (a lock per GPU held
+ *     for the duration of the call); calls from different PROCESSES have their own copies of the array.
  */
 int ultra_chain_mams_batch_noalloc(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_off,
                                    const int32_t *x, const int32_t *y, const int32_t *c, const int32_t *d,
@@ -203,8 +205,8 @@ int ultra_chain_nams_batch(ultra_ctx *ctx, int32_t n_inst, const int64_t *inst_o
  * as align.get_exact_alignment calls it per surviving location (modules/align.py:338-354): semi-global alignment of
  * query (the read) against target (the reconstructed exon sequence), end gaps free in both sequences at both ends,
  * affine gaps (a gap of length L costs gap_open + (L - 1) * gap_extend, penalties given as positive numbers),
- * substitution matrix matrix_create("ACGT", match, mismatch): A, C, G, T match case-insensitively, every other pair
- * of characters scores `mismatch`.
+ * substitution matrix matrix_create("ACGT", match, mismatch): A, C, G, T match case-insensitively, two different ones
+ * score `mismatch`, a pair with any other character (N, IUPAC) scores 0 (the matrix's wildcard row / column).
  * out score[p]                 best score (int32 arithmetic: what the 16-bit scan kernel gives unless it saturates and
  *                              what the 32-bit rerun gives then)
  * out end_query / end_ref      0-based end cell (on the last row or the last column)
@@ -363,6 +365,13 @@ int ultra_dindex_create(int device, const ultra_index *idx, ultra_dindex **out);
 void ultra_dindex_destroy(ultra_dindex *dix);
 const char *ultra_dindex_last_error(void);
 int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dix, const ultra_plan_request *rq);
+/* ultra_mam_stage_nams in its two halves, for callers that keep a batch's request in HBM (and for bench.py, whose timed
+ * step starts with its inputs resident in HBM): _upload_nams copies the request's arrays into the context's device
+ * buffers (synchronous; the host arrays may go away afterwards), _plan_resident runs the enumeration of
+ * classify_read_with_mams.py:180-300, :441-523 over them, sorts the pairs and leaves the context staged.  The uploaded
+ * request survives ultra_mam_run / _fetch and can be planned again; ultra_myers_stage / ultra_mam_stage replace it. */
+int ultra_mam_upload_nams(ultra_ctx *ctx, const ultra_plan_request *rq);
+int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dix);
 /* device copies of the staged batch's candidate arrays, for tests that compare the two planners: any pointer may be
  * NULL; capacities are the counts ultra_mam_counts reports */
 int ultra_mam_counts(const ultra_ctx *ctx, int32_t *n_inst, int32_t *n_cand, int32_t *n_pairs);

@@ -10,10 +10,13 @@
  * parasail.matrix_create("ACGT", match, mismatch).
  *
  * PARITY UNPINNED for everything that depends on parasail's tie-breaking (which of several optimal end cells and
- * which of several optimal paths its scan kernels report) and on its treatment of characters outside "ACGT"; the
- * SCORE is mathematically defined and is pinned against a plain O(mn) three-matrix DP in tests/test_oracle_affine.py.
+ * which of several optimal paths its scan kernels report); the SCORE is mathematically defined and is pinned against a
+ * plain O(mn) three-matrix DP in tests/test_oracle_affine.py.
  * Choices made here (and mirrored bit for bit by the HIP kernel):
- *   - A, C, G, T match case-insensitively (score `match`); every other pair of characters scores `mismatch`;
+ *   - A, C, G, T match case-insensitively (score `match`), two different ones score `mismatch`; a pair with any other
+ *     character (N, IUPAC codes) scores 0: matrix_create builds a (4 + 1) x (4 + 1) matrix whose extra "wildcard" row
+ *     and column are 0 and maps every byte outside the alphabet to it (parasail's published matrix_create; recalled, not
+ *     checkable here).  Such a pair is still written as 'X' in the edit script (cigar_to_seq treats '=' and 'X' alike);
  *   - end cell: the last row is scanned left to right, then the last column top to bottom; a later cell replaces
  *     the current best only when strictly better;
  *   - H: diagonal, then F (gap in the reference, consumes a query base, cigar 'I'), then E (consumes a reference
@@ -63,7 +66,7 @@ int oracle_sg_affine(const uint8_t *q, int m, const uint8_t *t, int n, int match
             const int f_is_ext = f_ext >= f_opn;
             F[j] = f_is_ext ? f_ext : f_opn;
             const int tc = sub_code(t[j - 1]);
-            const int32_t d = prev[j - 1] + ((qc >= 0 && qc == tc) ? match : mismatch);
+            const int32_t d = prev[j - 1] + ((qc >= 0 && tc >= 0) ? (qc == tc ? match : mismatch) : 0);
             int src = 0;
             int32_t h = d;
             if (F[j] > h) { h = F[j]; src = 1; }

@@ -49,6 +49,24 @@ def ops_to_cigar(ops):
     return "".join(out)
 
 
+def ins_range(query, target, expect):
+    """(I_min, I_max): fewest / most inserted query bases over every optimal global alignment of query with target,
+    whose distance must be `expect` (edlib_port.c: oracle_ins_range)."""
+    q = query.encode() if isinstance(query, str) else bytes(query)
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    a, b = C.c_int(), C.c_int()
+    rc = lib().oracle_ins_range(q, len(q), t, len(t), int(expect), C.byref(a), C.byref(b))
+    if rc != 0:
+        raise RuntimeError("oracle_ins_range failed rc=%d" % rc)
+    return a.value, b.value
+
+
+def set_length_prefilter(on):
+    """bench.py's cpu_baseline leg only: answer pairs whose query is more than k longer than the target without computing
+    them (edlib_port.c: oracle_length_prefilter).  Tests never set it."""
+    lib().oracle_set_length_prefilter(1 if on else 0)
+
+
 def hw_align(query, target, k, method="bitvector", want_path=True):
     """Oracle for edlib.align(query, target, mode='HW', task='path', k=k).
 

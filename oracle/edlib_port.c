@@ -285,6 +285,67 @@ static int nw_traceback_bits(const uint8_t *q, int m, const uint8_t *t, int L, i
     return rc == 0 ? n : rc;
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* Exposure of the unpinned tie rule: insertion counts over ALL optimal paths                   */
+/* ------------------------------------------------------------------------------------------- */
+
+/* Global alignments of q[0..m) with t[0..L) of cost `expect` (the first location of a hit): the smallest and the
+ * largest number of inserted query bases ('I' columns, "up" moves) over every optimal path - whatever tie rule, or
+ * Hirschberg split, a real edlib applies, its path's count lies in [*imin, *imax], and accuracy = (L - ED + I) / (L + I)
+ * grows with I.  Plain DP over the DAG of tight predecessors, restricted to |row - column| <= expect (no optimal
+ * path leaves that band).  Returns 0, -2 when the distance is not `expect`. */
+int oracle_ins_range(const uint8_t *q, int m, const uint8_t *t, int L, int expect, int *imin, int *imax)
+{
+    const int BIG = 1 << 29;
+    const int W = 2 * expect + 3;              /* band slots: column j of row i at slot j - i + expect + 1 */
+    int *D0 = (int *)malloc(sizeof(int) * W * 6);
+    if (!D0) return -1;
+    int *D1 = D0 + W, *lo0 = D1 + W, *lo1 = lo0 + W, *hi0 = lo1 + W, *hi1 = hi0 + W;
+    for (int s = 0; s < W; s++) { D0[s] = BIG; lo0[s] = 0; hi0[s] = 0; }
+    for (int j = 0; j <= L && j <= expect; j++) { D0[j + expect + 1] = j; lo0[j + expect + 1] = 0; hi0[j + expect + 1] = 0; }
+    for (int i = 1; i <= m; i++) {
+        for (int s = 0; s < W; s++) { D1[s] = BIG; lo1[s] = 0; hi1[s] = 0; }
+        int jlo = i - expect < 0 ? 0 : i - expect, jhi = i + expect > L ? L : i + expect;
+        for (int j = jlo; j <= jhi; j++) {
+            const int s = j - i + expect + 1;   /* this cell; (i-1, j) sits at s + 1 of the previous row, (i-1, j-1) at s */
+            const int up = D0[s + 1] < BIG ? D0[s + 1] + 1 : BIG;
+            const int diag = (j > 0 && D0[s] < BIG) ? D0[s] + (q[i - 1] != t[j - 1]) : BIG;
+            const int left = (j > jlo && D1[s - 1] < BIG) ? D1[s - 1] + 1 : BIG;
+            int v = up < diag ? up : diag;
+            if (left < v) v = left;
+            if (v >= BIG) continue;
+            int l = BIG, h = -1;
+            if (up == v) { if (lo0[s + 1] + 1 < l) l = lo0[s + 1] + 1; if (hi0[s + 1] + 1 > h) h = hi0[s + 1] + 1; }
+            if (diag == v) { if (lo0[s] < l) l = lo0[s]; if (hi0[s] > h) h = hi0[s]; }
+            if (left == v) { if (lo1[s - 1] < l) l = lo1[s - 1]; if (hi1[s - 1] > h) h = hi1[s - 1]; }
+            D1[s] = v; lo1[s] = l; hi1[s] = h;
+        }
+        int *x;
+        x = D0; D0 = D1; D1 = x; x = lo0; lo0 = lo1; lo1 = x; x = hi0; hi0 = hi1; hi1 = x;
+    }
+    int rc = 0;
+    const int s = L - m + expect + 1;
+    if (s < 0 || s >= W || D0[s] != expect) rc = -2;
+    else { *imin = lo0[s]; *imax = hi0[s]; }
+    {   /* D0 .. hi1 were swapped around: free the block's base address */
+        int *base = D0;
+        if (D1 < base) base = D1;
+        if (lo0 < base) base = lo0;
+        if (lo1 < base) base = lo1;
+        if (hi0 < base) base = hi0;
+        if (hi1 < base) base = hi1;
+        free(base);
+    }
+    return rc;
+}
+
+/* CPU-BASELINE switch only (bench.py's cpu_baseline leg sets it; every test leaves it 0, so that the checker computes
+ * every cell): 1 = answer -1 at once when the query is more than k longer than the target, which is what edlib's band
+ * amounts to for those pairs and what libultra_hip does at stage time - a baseline without it would be charged for
+ * cells neither edlib nor the GPU path computes. */
+int oracle_length_prefilter = 0;
+void oracle_set_length_prefilter(int on) { oracle_length_prefilter = on; }
+
 /* Same contract as oracle_hw_bruteforce. want_path = 0 skips the traceback (first_ins = 0). */
 int oracle_hw_bitvector(const uint8_t *q, int m, const uint8_t *t, int n, int k,
                         int *ed, int *n_loc, int *starts, int *ends, int cap,
@@ -294,6 +355,7 @@ int oracle_hw_bitvector(const uint8_t *q, int m, const uint8_t *t, int n, int k,
     if (m <= 0 || n <= 0) return 0;
     int B = (m + 63) / 64;
     if (k < 0 || k > m) k = m; /* a semi-global hit never costs more than the whole query */
+    if (oracle_length_prefilter && m - n > k) return 0;
     word_t *peq = build_peq(q, m, B, 0);
     search_res F = sweep(peq, B, m, t, +1, n, k, 0, ends, cap);
     free(peq);

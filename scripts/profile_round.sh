@@ -2,12 +2,12 @@
 # One round's profile evidence, on the GPU box from the repo root:  bash scripts/profile_round.sh r01
 # Kernel times (--kernel-trace --stats), HBM traffic (separate --pmc passes, FETCH_SIZE / WRITE_SIZE) and the
 # SQ instruction/occupancy counters of the same bench command.  GPU_MAX_HW_QUEUES is exported here because the
-# profiler initialises HIP before bench.py could set it.  8 queues here (bench.py's default is 16, for the end-to-end
-# pipeline; the device-resident step is the same with both): under rocprofv3 with 16, two launch lanes of a context
-# ended up on one hardware queue and their kernels ran one after the other in the trace.
+# profiler initialises HIP before bench.py could set it: 16 queues, bench.py's own default, clamped to the
+# pool's limit of 32 and exported under both names (ultra_amd/hwq.py: the bench line then records the count in force).
 set -o pipefail
 tag=${1:-r01}
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=${ULTRA_HW_QUEUES:-8}
+q=${ULTRA_HW_QUEUES:-16}; [ "$q" -ge 1 ] 2>/dev/null || q=16; [ "$q" -gt 32 ] && q=32
+export TMPDIR=/tmp GPU_MAX_HW_QUEUES=$q ULTRA_HW_QUEUES=$q
 out=gpurun_out/prof_$tag
 mkdir -p $out
 B="python3 bench.py --steps 10 --warmup 2 --cpu-seconds 0 --check 0 --e2e-rounds 0 --micro 0"

@@ -142,6 +142,71 @@ def test_align_single_is_independent_of_gpu_batching(ctx, tmp_path):
     assert all(f[11] in ("0", "60") for f in primaries)
 
 
+def test_one_read_outside_the_envelope_does_not_take_the_batch_down(ctx, tmp_path):
+    """A read the GPU path cannot take (here: more distinct bytes than the 36 a batch may hold) fails the launch it is
+    part of; align_single then isolates it, reports it unaligned with a line in uLTRA_batch_N.stderr, and every other
+    read of the batch gets exactly the rows it gets without it.  A 40 kb read contained in a 50 kb exon (queries
+    beyond 32768 rows, classify_read_with_mams.py:374-377) is NOT such a read: it is aligned."""
+    from ultra_amd import align, seed_wrapper, synth
+    world = synth.make_world(seed=78, n_genes=30, n_chr=2)
+    rng = np.random.RandomState(4)
+    # one very long exon, hit by a very long read
+    chr_id = 0
+    big = (chr_id, 9000000, 9050000)
+    big_seq = synth._rand_seq(rng, big[2] - big[1])
+    key = synth.key_of(*big)
+    world.part_seq[big] = big_seq
+    world.ref_segment_sequences[key] = big_seq
+    world.parts_to_segments[key] = align._array('L', list(big))
+    world.segment_to_gene[key] = {"gene_big"}
+    world.gene_to_small_segments["gene_big"] = align._array('L')
+    sims = [synth.simulate_instance(world, rng, "ont_cdna") for _ in range(60)]
+    chr_ids = sorted({p[0] for p in world.part_seq})
+    data = (world.ref_segment_sequences, world.ref_flank_sequences, {}, {}, {c: {} for c in chr_ids}, {c: set() for c in chr_ids},
+            world.parts_to_segments, world.segment_to_gene, world.gene_to_small_segments, {c: 100000 for c in chr_ids},
+            {}, {str(c): c for c in chr_ids}, {c: "chr%d" % c for c in chr_ids})
+    state = align.AlignState(data, ctx=ctx, device=0)
+    records = [["read%d" % i, read, None, [seed_wrapper.format_hit(m) for m in sol], []] for i, (read, sol, _) in enumerate(sims)]
+    # the long read: 40 kb of the exon with a few edits, seeds = its exact stretches (one NAM per 500 bases is plenty)
+    from tests import helpers
+    long_read = helpers.mutate(rng, big_seq[5000:45000], 0.01)
+    hits = []
+    for c in range(0, len(long_read) - 40, 2000):
+        piece = long_read[c:c + 25]
+        at = big_seq.find(piece)
+        if at >= 0 and big_seq.find(piece, at + 1) < 0:
+            hits.append("%d^%d^%d\t%d\t%d\t%d" % (chr_id, big[1], big[2], at + 1, c + 1, 25))
+    assert len(hits) > 10
+    long_rec = ["long_read", long_read, None, hits, []]
+    # the read no batch can hold: its own 40 distinct bytes on top of the index's
+    weird = sims[7][0][:200] + "".join(chr(c) for c in range(48, 88)) + sims[7][0][200:]
+    weird_rec = ["weird_read", weird, None, records[7][3], []]
+    args = types.SimpleNamespace(outfolder=str(tmp_path), index="", reduce_read_ployA=8, max_intron=1200000, dropoff=0.95, max_loc=5,
+                                 min_acc=0.6, alignment_threshold=0.5, non_covered_cutoff=15, downstream=_stub_downstream(),
+                                 ultra_state=state, gpu_batch_reads=65536)
+
+    def run(recs):
+        qin, qout, qcnt = queue.Queue(), queue.Queue(), queue.Queue()
+        qin.put([1, recs]); qin.put(None)
+        align.align_single(0, qin, qout, qcnt, args)
+        return qout.get(), qcnt.get()
+    try:
+        clean_rows, clean_counts = run(records + [long_rec])
+        log_clean = open(os.path.join(str(tmp_path), "uLTRA_batch_0.stderr")).read()
+        mixed = records[:20] + [weird_rec] + records[20:] + [long_rec]
+        rows, counts = run(mixed)
+        log = open(os.path.join(str(tmp_path), "uLTRA_batch_0.stderr")).read()
+    finally:
+        state.close()
+    assert "weird_read" not in log_clean and "weird_read" in log and "unaligned" in log
+    weird_rows = [r for r in rows if r.startswith("weird_read\t")]
+    assert len(weird_rows) == 1 and "unaligned" in weird_rows[0]
+    assert [r for r in rows if not r.startswith("weird_read\t")] == clean_rows
+    assert counts[1:] == clean_counts[1:]
+    long_rows = [r for r in clean_rows if r.startswith("long_read\t")]
+    assert long_rows and "unaligned" not in long_rows[0] and "9000000" in long_rows[0]
+
+
 @pytest.mark.parametrize("gpu_batch", [65536, 7])
 def test_align_single_equals_the_reference_on_sirv(ctx, tmp_path, gpu_batch):
     """tests/golden/align_single_golden.json: the reference's own align_single (modules/align.py:392-560) run on the
@@ -233,6 +298,9 @@ def test_pc_main_runs_the_reference_protocol(ctx, tmp_path, per_gpu):
                                  alignment_threshold=0.5, non_covered_cutoff=15, gpus=1, gpu_batch_reads=1500, downstream=down,
                                  consumers_per_gpu=per_gpu)
     totals = pc.main(reads_path, seeds_path, sam_path, args)
+    # the consumers are spawned children: they must run with the benched queue count, not HIP's default of 4
+    for w in range(per_gpu):
+        assert "GPU_MAX_HW_QUEUES=16" in open(os.path.join(out, "uLTRA_batch_%d.stderr" % w)).read()
     rows = open(sam_path).read().splitlines(True)
     # the same records through align_single in this process
     with open(reads_path) as fh:

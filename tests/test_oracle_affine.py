@@ -21,7 +21,8 @@ def plain_score(q, t, match=2, mismatch=-2, go=3, ge=1):
             E[i][j] = max(E[i][j - 1] - ge, H[i][j - 1] - go)
             F[i][j] = max(F[i - 1][j] - ge, H[i - 1][j] - go)
             a, b = canon(q[i - 1]), canon(t[j - 1])
-            H[i][j] = max(H[i - 1][j - 1] + (match if a is not None and a == b else mismatch), E[i][j], F[i][j])
+            sub = 0 if a is None or b is None else match if a == b else mismatch     # wildcard row / column of matrix_create: 0
+            H[i][j] = max(H[i - 1][j - 1] + sub, E[i][j], F[i][j])
     return max(max(H[m][1:]), max(H[i][n] for i in range(1, m + 1)))
 
 
@@ -33,7 +34,8 @@ def rescore(ops, q, t, match=2, mismatch=-2, go=3, ge=1):
         if op in (0, 3):
             same = q[i].upper() == t[j].upper() and q[i].upper() in "ACGT"
             assert (op == 0) == same
-            cols.append("M" if same else "X"); i += 1; j += 1
+            wild = q[i].upper() not in "ACGT" or t[j].upper() not in "ACGT"
+            cols.append("M" if same else "W" if wild else "X"); i += 1; j += 1
         elif op == 1:
             cols.append("I"); i += 1
         else:
@@ -54,6 +56,8 @@ def rescore(ops, q, t, match=2, mismatch=-2, go=3, ge=1):
             score += match
         elif c == "X":
             score += mismatch
+        elif c == "W":
+            pass
         else:
             score -= ge if prev == c else go
         prev = c
@@ -87,3 +91,8 @@ def test_known_small_cases():
     r = cport.sg_affine("ACGTACGT", "ACGACGT")       # one deleted base in the reference: gap open 3
     assert r["score"] == 2 * 7 - 3
     assert cport.sg_affine("AAAA", "CCCC")["score"] <= 0
+    # worked by hand: N pairs with anything at 0.  ACNT in TTACGTTT: A=, C=, N/G 0, T= -> 6 (a mismatch would give 2 + 2 - 2 + 2 = 4)
+    r = cport.sg_affine("ACNT", "TTACGTTT")
+    assert (r["score"], r["cigar"]) == (6, "2D2=1X1=2D")
+    assert cport.sg_affine("NNNN", "ACGT")["score"] == 0 and cport.sg_affine("acgt", "ACGT")["score"] == 8
+    assert cport.sg_affine("ACGNACG", "ACGTACG")["score"] == 12 and cport.sg_affine("ACGAACG", "ACGTACG")["score"] == 10

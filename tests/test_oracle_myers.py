@@ -82,3 +82,62 @@ def test_batch_driver_matches_single_calls():
         o = int(loc_off[p])
         assert r["locations"] == list(zip(st[o:o + nl[p]].tolist(), en[o:o + nl[p]].tolist()))
         assert r["insertions"] == fi[p]
+
+
+def _all_optimal_ins_counts(q, t):
+    """Every insertion count an optimal global alignment of q with t can have (plain DP + walk over tight moves)."""
+    m, n = len(q), len(t)
+    D = [[0] * (n + 1) for _ in range(m + 1)]
+    for i in range(m + 1):
+        for j in range(n + 1):
+            if i == 0 or j == 0:
+                D[i][j] = i + j
+            else:
+                D[i][j] = min(D[i - 1][j - 1] + (q[i - 1] != t[j - 1]), D[i - 1][j] + 1, D[i][j - 1] + 1)
+    memo = {}
+
+    def counts(i, j):
+        if (i, j) not in memo:
+            if i == 0 and j == 0:
+                memo[(i, j)] = {0}
+            else:
+                s = set()
+                if i > 0 and D[i - 1][j] + 1 == D[i][j]:
+                    s |= {c + 1 for c in counts(i - 1, j)}
+                if j > 0 and D[i][j - 1] + 1 == D[i][j]:
+                    s |= counts(i, j - 1)
+                if i > 0 and j > 0 and D[i - 1][j - 1] + (q[i - 1] != t[j - 1]) == D[i][j]:
+                    s |= counts(i - 1, j - 1)
+                memo[(i, j)] = s
+        return memo[(i, j)]
+    return D[m][n], counts(m, n)
+
+
+def test_insertion_range_over_all_optimal_paths():
+    """oracle_ins_range brackets every optimal path's insertion count (the exposure of the unpinned traceback rule)."""
+    from oracle import cport
+    assert cport.ins_range("ACTG", "ACT", 1) == (1, 1)
+    assert cport.ins_range("AB", "BA", 2) == (0, 1)        # two substitutions, or insert / match / delete
+    rng = np.random.RandomState(15)
+    wide = 0
+    for it in range(1500):
+        alpha = ["ACGT", "AC", "A"][it % 3]
+        n = int(rng.randint(1, 14)); m = int(rng.randint(1, 14))
+        t = helpers.rand_seq(rng, n, alpha)
+        q = helpers.mutate(rng, t, 0.3) or "A" if it % 2 else helpers.rand_seq(rng, m, alpha)
+        ed, cs = _all_optimal_ins_counts(q, t)
+        lo, hi = cport.ins_range(q, t, ed)
+        assert (lo, hi) == (min(cs), max(cs)), (q, t)
+        wide += hi > lo
+    assert wide > 100
+    # the oracle's own path (rule: up, then left, then diagonal) lies inside the range, on real-sized hits
+    for it in range(200):
+        t = helpers.rand_seq(rng, int(rng.randint(200, 900)))
+        m = int(rng.randint(20, 180)); a = int(rng.randint(0, len(t) - m))
+        q = helpers.mutate(rng, t[a:a + m], float(rng.choice([0.03, 0.1, 0.25]))) or "A"
+        r = cport.hw_align(q, t, int(0.4 * min(len(q), len(t))))
+        if r["editDistance"] < 0:
+            continue
+        s, e = r["locations"][0]
+        lo, hi = cport.ins_range(q, t[s:e + 1], r["editDistance"])
+        assert lo <= r["insertions"] <= hi

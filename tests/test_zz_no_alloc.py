@@ -49,6 +49,32 @@ def test_noalloc_matches_the_allocating_entry_point_twice_in_a_row(ctx):
         assert idx[o:o + ln[i]].tolist() == want and np.float64(val[i]).tobytes() == np.float64(wv).tobytes()
 
 
+def _free_device_bytes():
+    """hipMemGetInfo through the HIP runtime the library has loaded."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_noalloc_allocates_no_device_memory(ctx):
+    """Free device memory is the same before and after calls that run every solver, the n log n one included (whose
+    tree arrays are the largest piece of scratch), on inputs larger than anything the context has seen."""
+    rng = np.random.RandomState(73)
+    warm = _batch(rng, [4, 30], [100])
+    ctx.chain_mams_batch(*warm, noalloc=True)               # module load, first use of the streams
+    before = _free_device_bytes()
+    sizes = [int(s) for s in rng.choice([1, 9, 48, 49, 199, 201, 450, 900, 2500], size=400)]
+    batch = _batch(rng, sizes, [300, 3000])
+    for kw in (dict(solver=0), dict(solver=2), dict(solver=1)):
+        ctx.chain_mams_batch(*batch, noalloc=True, **kw)
+    assert _free_device_bytes() == before
+    # the allocating entry point on the same input does take memory (the check can see an allocation)
+    ctx.chain_mams_batch(*batch, solver=2)
+    assert _free_device_bytes() < before
+
+
 def test_noalloc_rejects_what_does_not_fit(ctx):
     from ultra_amd import lib
     cap = ctx.lib.ultra_chain_noalloc_capacity()

@@ -160,6 +160,7 @@ def mam_stage_batch(reads, locations, index, min_acc, ctx=None):
 import itertools
 import os
 import pickle
+import sys
 from array import array as _array
 
 INDEX_FILES = ("ref_segment_sequences", "ref_flank_sequences", "splices_to_transcripts", "transcripts_to_splices",
@@ -327,6 +328,32 @@ class Downstream(object):
         return [self.exact_alignment(*j) for j in jobs]
 
 
+def _pyset_matches_interpreter(so, n_sets=24):
+    """ultra_pyset_order (the library's restatement of CPython's set iteration order for int triples) against this
+    interpreter's own sets: a few random sets of every table size the planners meet."""
+    import ctypes as C
+    import random
+    rnd = random.Random(20241008)
+    for t in range(n_sets):
+        n = (2, 3, 5, 8, 13, 21, 40, 100)[t % 8]
+        triples = []
+        seen = set()
+        while len(triples) < n:
+            v = (rnd.randrange(1, 30), rnd.randrange(0, 250000000), rnd.randrange(0, 250000000))
+            if v not in seen:
+                seen.add(v); triples.append(v)
+        s = set()
+        for v in triples:
+            s.add(v)
+        flat = (C.c_int64 * (3 * n))(*[x for v in triples for x in v])
+        order = (C.c_int32 * n)()
+        if so.ultra_pyset_order(flat, n, order) != 0:
+            return False
+        if [triples[order[k]] for k in range(n)] != list(s):
+            return False
+    return True
+
+
 class AlignState(object):
     """What an align_single worker keeps between batches: index dictionaries, packed index on host and GPU, context."""
 
@@ -337,13 +364,24 @@ class AlignState(object):
          self.all_splice_pairs_annotations, self.all_splice_sites_annotations, self.parts_to_segments, self.segment_to_gene,
          self.gene_to_small_segments, self.max_intron_chr, self.ref_exon_sequences, self.chr_to_id, self.id_to_chr) = data
         self.ctx = ctx or _lib.default_context()
+        self.notes = []                 # lines for the worker's uLTRA_batch_N.stderr
+        self.python = "%d.%d.%d" % sys.version_info[:3]
+        # Where the reference's candidate order follows the iteration order of a Python set (hit segments with equal
+        # starts), the planners reproduce CPython's tuple hash and set probing (csrc/pyset.h, written against 3.10).  The
+        # order uLTRA itself would produce is the running interpreter's: check the restatement against it, here and now.
+        if not _pyset_matches_interpreter(_lib.load()):
+            raise RuntimeError("ultra_amd: csrc/pyset.h does not reproduce the set iteration order of this interpreter (Python %s); "
+                               "the MAM stage would pick other partial segments than uLTRA does under it" % self.python)
         self.native = native_index.NativeIndex(self.ref_segment_sequences, self.ref_flank_sequences, self.parts_to_segments,
                                                self.segment_to_gene, self.gene_to_small_segments)
         dev = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
         try:
             self.dindex = native_index.DeviceIndex(self.native, dev)
-        except _lib.UltraError:
+        except _lib.UltraError as e:
+            if e.code != -4:            # out of memory, wrong device, ...: not something to work around silently
+                raise
             self.dindex = None          # index outside the device planner's envelope: batches are planned on the host
+            self.notes.append("device planner not usable for this index (%s): batches are planned on the host" % e)
         self._parts = {}
         self.n_quadratic = self.n_nlogn = 0
 
@@ -479,6 +517,32 @@ def align_reads_batch(records, state, args, downstream):
     return out, counts
 
 
+def align_reads_isolated(records, state, args, downstream, log=None):
+    """align_reads_batch with per-read isolation.  An input outside the library's envelope (ULTRA_E_UNSUPPORTED: more than
+    36 distinct bytes in a batch, an instance beyond the chainers' or the MAM builder's LDS limits, a base-level
+    alignment beyond the trace budget) fails the WHOLE launch it is part of; the reference aligns any read.  The batch
+    is then cut in halves until the offending reads stand alone; those are reported unaligned, with a line in the
+    worker's log, and every other read of the batch gets exactly the rows it would have had (results do not depend on
+    the grouping: test_align_single_is_independent_of_gpu_batching)."""
+    from . import lib as _lib
+    try:
+        return align_reads_batch(records, state, args, downstream)
+    except _lib.UltraError as e:
+        if e.code != -4:
+            raise
+        if len(records) == 1:
+            acc, seq, qual = records[0][0], records[0][1], records[0][2]
+            if log is not None:
+                log.write("ultra_amd: read %s (%d bases) is outside the GPU path's envelope and is reported unaligned: %s\n" % (acc, len(seq), e))
+                log.flush()
+            seq_mod, qual_mod = remove_read_polyA_ends(seq, qual, args.reduce_read_ployA, 1)
+            return [[downstream.sam_entry(acc, seq_mod, qual_mod, '*', 'unaligned', [], '*', '*', '*', False, False, 0)]], [0] * 8
+        half = len(records) // 2
+        rows_a, counts_a = align_reads_isolated(records[:half], state, args, downstream, log)
+        rows_b, counts_b = align_reads_isolated(records[half:], state, args, downstream, log)
+        return rows_a + rows_b, [a + b for a, b in zip(counts_a, counts_b)]
+
+
 def align_single(process_id, input_queue, output_sam_buffer, classification_and_aln_cov, args):
     """Drop-in for modules/align.py:392 (started by pc.py:81).  One worker drives one GPU: LOCAL_RANK, or
     process_id modulo the number of GPUs.  args may carry, beyond the reference's fields: gpu_batch_reads (reads taken
@@ -495,6 +559,12 @@ def align_single(process_id, input_queue, output_sam_buffer, classification_and_
     group_reads = int(getattr(args, "gpu_batch_reads", 65536))
     log_path = os.path.join(args.outfolder, "uLTRA_batch_{0}.stderr".format(process_id))
     warning_log_file = open(log_path, "w")
+    warning_log_file.write("ultra_amd: GPU worker %d on device %s, GPU_MAX_HW_QUEUES=%s, Python %s\n"
+                           % (process_id, os.environ.get("LOCAL_RANK", "?"), os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)"),
+                              state.python))
+    for note in state.notes:
+        warning_log_file.write("ultra_amd: %s\n" % note)
+    warning_log_file.flush()
     classification_list = [0, 0, 0, 0, 0, 0, 0, 0]
     processed = 0
     done = False
@@ -513,7 +583,7 @@ def align_single(process_id, input_queue, output_sam_buffer, classification_and_
         if not group:
             continue
         records = [tuple(b) for batch in group for b in batch[1]]
-        rows, counts = align_reads_batch(records, state, args, downstream)
+        rows, counts = align_reads_isolated(records, state, args, downstream, warning_log_file)
         for i in range(8):
             classification_list[i] += counts[i]
         at = 0

@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(64) k_affine_fill(AffArgs a)
                 const int32_t f_ext = upF - ge, f_opn = upH - go;
                 const bool f_is_ext = f_ext >= f_opn;
                 const int32_t F = f_is_ext ? f_ext : f_opn;
-                int32_t h = Hdiag + ((qc >= 0 && qc == tc) ? a.match : a.mismatch);
+                // matrix_create("ACGT", match, mismatch): a character outside the alphabet maps to the matrix's wildcard
+                // row / column, whose entries are 0 (N against anything neither earns nor costs)
+                int32_t h = Hdiag + ((qc >= 0 && tc >= 0) ? (qc == tc ? a.match : a.mismatch) : 0);
                 int src = 0;
                 if (F > h) { h = F; src = 1; }
                 if (E > h) { h = E; src = 2; }

@@ -782,8 +782,10 @@ extern "C" int ultra_chain_mams_batch(ultra_ctx *ctx, int32_t n_inst, const int6
 // ---- the one entry point that allocates nothing ----------------------------------------------------------------
 // ultra_chain_mams_batch needs device memory beyond its inputs and outputs: staging copies of the MAM arrays, the
 // launch lists, the result vectors and the search-tree arrays of the n log n solver.  Callers that must not allocate
-// (HIP graph capture, serving loops, harnesses that forbid hipMalloc) get the same kernels on a fixed buffer that is
-// part of the library's image: every GPU holds its own copy at its own address until the process ends.
+// device memory (serving loops with a fixed memory budget, harnesses that forbid hipMalloc) get the same kernels on a
+// fixed buffer that is part of the library's image: every GPU holds its own copy at its own address until the process
+// ends.  The call is synchronous (host copies, one stream synchronisation): it allocates nothing, but it is not
+// something to record into a HIP graph as it stands.
 constexpr size_t kNoAllocBytes = (size_t)8 << 20;
 static __device__ __align__(256) uint8_t scratch[kNoAllocBytes];
 
@@ -791,6 +793,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 uint8_t *g_scratch_ptr[kMaxDevices] = {}; // device address of `scratch` on each GPU (the symbol itself is a host-side stand-in)
 std::mutex g_scratch_mu;
+std::mutex g_scratch_call_mu[kMaxDevices]; // one call at a time per GPU: every context of a device shares that device's array
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 } // namespace
 
@@ -845,6 +848,9 @@ extern "C" int ultra_chain_mams_batch_noalloc(ultra_ctx *ctx, int32_t n_inst, co
                                                      "split the batch or use ultra_chain_mams_batch");
     std::vector<int32_t> h_cnt(ni);
     for (int32_t i = 0; i < n_inst; i++) h_cnt[(size_t)i] = (int32_t)(inst_off[i + 1] - inst_off[i]);
+    // The call returns with everything done (it ends with a stream synchronisation), so holding the device's lock for
+    // its duration serialises callers on different contexts / threads instead of letting them corrupt each other.
+    std::lock_guard<std::mutex> one_at_a_time(g_scratch_call_mu[ctx->device]);
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     ultra_drain_guard drain(ctx);

@@ -107,6 +107,9 @@ struct MamState {
     int64_t *pinned_base = nullptr;  // pinned copy of instbase (first MAM slot of every instance, then the total), read
     size_t pinned_cap = 0;           // back while the Myers passes still run; entries
     std::vector<int32_t> h_slots;    // slots per instance = upper bound of its MAM count
+    bool up_valid = false;           // an uploaded request (ultra_mam_upload_nams) lies in d_nam* / my.raw
+    int32_t up_ni = 0;
+    int64_t up_nnam = 0, up_read_bytes = 0;
     bool has_chr = false;            // chr[] holds the chromosome id of every candidate (needed for chain_chr in the fetch)
     DevBuf chr, ckind, cchr;
     // device planner (dplan.hip): the request on the device, per-instance counts, overflow list, counters, scan scratch

@@ -716,14 +716,15 @@ extern "C" int ultra_dindex_create(int device, const ultra_index *ix, ultra_dind
     return ULTRA_OK;
 }
 
-// Plans and stages one batch on the device: afterwards the context is in the state ultra_mam_stage leaves it in.
-extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, const ultra_plan_request *rq)
+// The request of a batch (NAM chains + reads) goes up into the context's buffers and stays there: ultra_mam_plan_resident
+// plans from it any number of times.
+extern "C" int ultra_mam_upload_nams(ultra_ctx *ctx, const ultra_plan_request *rq)
 {
-    if (!ctx || !dx || !rq) return ULTRA_E_ARG;
+    if (!ctx || !rq) return ULTRA_E_ARG;
     MamState &m = ctx->mam;
     MyersState &st = ctx->my;
     m.staged = false; m.ran = false; st.staged = false; st.ran = false;
-    if (dx->device != ctx->device) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_stage_nams: index and context are on different devices");
+    m.up_valid = false;
     const int32_t ni = rq->n_inst;
     if (ni < 0) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_stage_nams: negative instance count");
     if (ni > 0 && (!rq->inst_nam_off || !rq->read_off || !rq->reads)) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_stage_nams: null array");
@@ -738,6 +739,41 @@ extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, cons
         n_nam = rq->inst_nam_off[ni]; read_bytes = rq->read_off[ni];
         if (n_nam > 0 && (!rq->nam_part || !rq->nam_x || !rq->nam_y)) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_stage_nams: null NAM array");
     }
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    ultra_drain_guard drain(ctx);
+    const size_t NI = (size_t)std::max(ni, 1), NN = (size_t)std::max<int64_t>(n_nam, 1);
+    ULTRA_HIP_CHECK(ctx, st.raw.ensure((size_t)read_bytes + 16));
+    ULTRA_HIP_CHECK(ctx, m.d_namoff.ensure((NI + 1) * 8)); ULTRA_HIP_CHECK(ctx, m.d_readoff.ensure((NI + 1) * 8));
+    ULTRA_HIP_CHECK(ctx, m.d_nampart.ensure(NN * 24)); ULTRA_HIP_CHECK(ctx, m.d_namx.ensure(NN * 8)); ULTRA_HIP_CHECK(ctx, m.d_namy.ensure(NN * 8));
+    if (ni > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.raw.p, rq->reads, (size_t)read_bytes, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_namoff.p, rq->inst_nam_off, (NI + 1) * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_readoff.p, rq->read_off, (NI + 1) * 8, hipMemcpyHostToDevice, s));
+    }
+    if (n_nam > 0) {
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_nampart.p, rq->nam_part, (size_t)n_nam * 24, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_namx.p, rq->nam_x, (size_t)n_nam * 8, hipMemcpyHostToDevice, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_namy.p, rq->nam_y, (size_t)n_nam * 8, hipMemcpyHostToDevice, s));
+    }
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // the caller's arrays may go away
+    drain.dismiss();
+    m.up_ni = ni; m.up_nnam = n_nam; m.up_read_bytes = read_bytes; m.up_valid = true;
+    return ULTRA_OK;
+}
+
+// Plans and stages the uploaded batch on the device: afterwards the context is in the state ultra_mam_stage leaves it
+// in.  Everything it reads lies in HBM (the request, the resident index); what comes back to the host are counts.
+extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
+{
+    if (!ctx || !dx) return ULTRA_E_ARG;
+    MamState &m = ctx->mam;
+    MyersState &st = ctx->my;
+    m.staged = false; m.ran = false; st.staged = false; st.ran = false;
+    if (!m.up_valid) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_plan_resident: no uploaded batch (ultra_mam_upload_nams)");
+    if (dx->device != ctx->device) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_stage_nams: index and context are on different devices");
+    const int32_t ni = m.up_ni;
+    const int64_t n_nam = m.up_nnam, read_bytes = m.up_read_bytes;
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     ultra_drain_guard drain(ctx);
@@ -777,19 +813,9 @@ extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, cons
         m.staged = true;
         return ULTRA_OK;
     }
-    // ---- request up; new symbols of the reads get the next codes ----
-    const size_t NI = (size_t)ni, NN = (size_t)std::max<int64_t>(n_nam, 1);
-    ULTRA_HIP_CHECK(ctx, st.raw.ensure((size_t)read_bytes + 16));
-    ULTRA_HIP_CHECK(ctx, m.d_namoff.ensure((NI + 1) * 8)); ULTRA_HIP_CHECK(ctx, m.d_readoff.ensure((NI + 1) * 8));
-    ULTRA_HIP_CHECK(ctx, m.d_nampart.ensure(NN * 24)); ULTRA_HIP_CHECK(ctx, m.d_namx.ensure(NN * 8)); ULTRA_HIP_CHECK(ctx, m.d_namy.ensure(NN * 8));
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.raw.p, rq->reads, (size_t)read_bytes, hipMemcpyHostToDevice, s));
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_namoff.p, rq->inst_nam_off, (NI + 1) * 8, hipMemcpyHostToDevice, s));
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_readoff.p, rq->read_off, (NI + 1) * 8, hipMemcpyHostToDevice, s));
-    if (n_nam > 0) {
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_nampart.p, rq->nam_part, (size_t)n_nam * 24, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_namx.p, rq->nam_x, (size_t)n_nam * 8, hipMemcpyHostToDevice, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.d_namy.p, rq->nam_y, (size_t)n_nam * 8, hipMemcpyHostToDevice, s));
-    }
+    // ---- new symbols of the reads get the next codes ----
+    const size_t NI = (size_t)ni;
+    (void)n_nam;
     uint32_t *d_mask = (uint32_t *)(st.lut.as<uint8_t>() + 256);
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_mask, 0, 32, s));
     ultra_launch_presence(s, st.raw.as<uint8_t>(), read_bytes, d_mask);
@@ -904,4 +930,13 @@ extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, cons
     m.n_cand = (int32_t)nc; m.n_inst = ni; m.max_cand = max_c; m.has_chr = true;
     m.staged = true;
     return ULTRA_OK;
+}
+
+extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, const ultra_plan_request *rq)
+{
+    if (!ctx || !dx || !rq) return ULTRA_E_ARG;
+    if (dx->device != ctx->device) return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_stage_nams: index and context are on different devices");
+    const int rc = ultra_mam_upload_nams(ctx, rq);
+    if (rc != ULTRA_OK) return rc;
+    return ultra_mam_plan_resident(ctx, dx);
 }

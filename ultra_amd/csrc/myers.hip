@@ -2312,6 +2312,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
 {
     MyersState &st = ctx->my;
     st.staged = false; st.ran = false;
+    ctx->mam.up_valid = false; // st.raw is about to hold this batch's arena instead of an uploaded request's reads
     if (n_pairs < 0 || (n_pairs > 0 && (!arena || !q_off || !q_len || !t_off || !t_len || !k)))
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_myers_stage: null pointer or negative pair count");
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));

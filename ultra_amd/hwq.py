@@ -15,22 +15,27 @@ POOL_MAX = 32     # the GPU pool refuses more
 # same at 8 and 16; 24 queues are more than the hardware schedules at once (35 ms per step instead of 24).
 
 
+def _parse(raw):
+    try:
+        n = int(raw)
+    except (TypeError, ValueError):
+        return None
+    return min(n, POOL_MAX) if n > 0 else None
+
+
 def hw_queues(default=16):
-    """ULTRA_HW_QUEUES parsed and clamped to 1..32; anything unparsable falls back to HIP's own default."""
+    """ULTRA_HW_QUEUES parsed and clamped to 1..32 (anything unparsable falls back to HIP's own default), else `default`.
+    A launcher that initialises HIP before this process can (rocprofv3 does) must export BOTH GPU_MAX_HW_QUEUES and
+    ULTRA_HW_QUEUES with the same value (scripts/profile_round.sh does): the first is what HIP reads, the second keeps
+    this module - and through it the library's lane count and the bench line - on the count that is in force."""
     raw = os.environ.get("ULTRA_HW_QUEUES")
     if raw is None:
         return default
-    try:
-        n = int(raw)
-    except ValueError:
-        return HIP_DEFAULT
-    if n <= 0:
-        return HIP_DEFAULT
-    return min(n, POOL_MAX)
+    return _parse(raw) or HIP_DEFAULT
 
 
 def export_hw_queues(default=16):
-    """Sets GPU_MAX_HW_QUEUES for this process (call before the first HIP call) and returns the value."""
+    """Sets GPU_MAX_HW_QUEUES for this process (call before the first HIP call) and returns the value in force."""
     n = hw_queues(default)
     os.environ["GPU_MAX_HW_QUEUES"] = str(n)
     return n

@@ -25,7 +25,8 @@ EXPORTS = [
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
     "ultra_index_create", "ultra_index_destroy", "ultra_plan_create", "ultra_plan_input", "ultra_plan_cands",
     "ultra_plan_destroy", "ultra_plan_last_error", "ultra_pyset_order",
-    "ultra_dindex_create", "ultra_dindex_destroy", "ultra_dindex_last_error", "ultra_mam_stage_nams", "ultra_mam_counts",
+    "ultra_dindex_create", "ultra_dindex_destroy", "ultra_dindex_last_error", "ultra_mam_stage_nams", "ultra_mam_upload_nams",
+    "ultra_mam_plan_resident", "ultra_mam_counts",
     "ultra_mam_fetch_plan",
     "ultra_pipe_create", "ultra_pipe_destroy", "ultra_pipe_last_error", "ultra_pipe_submit", "ultra_pipe_pending",
     "ultra_pipe_wait", "ultra_pipe_release", "ultra_pipe_timing", "ultra_sg_affine_batch",
@@ -146,6 +147,8 @@ def load():
     lib.ultra_dindex_last_error.argtypes = []
     lib.ultra_dindex_last_error.restype = C.c_char_p
     lib.ultra_mam_stage_nams.argtypes = [vp, vp, C.POINTER(PlanRequest)]
+    lib.ultra_mam_upload_nams.argtypes = [vp, C.POINTER(PlanRequest)]
+    lib.ultra_mam_plan_resident.argtypes = [vp, vp]
     lib.ultra_mam_counts.argtypes = [vp, i32p, i32p, i32p]
     lib.ultra_mam_fetch_plan.argtypes = [vp, i64p, i32p, i64p, i64p, u8p, i32p, i32p, i32p, i32p, i32p, i32p, i32p,
                                          i64p, i32p, i64p, i32p, i32p]
@@ -338,9 +341,10 @@ class Context(object):
         self._staged_n = int(inp.contents.n_pairs)
         self._check(self.lib.ultra_mam_stage(self._h, inp))
 
-    def mam_stage_nams(self, dindex, nam_off, nam_part, nam_x, nam_y, reads, read_off):
+    def mam_stage_nams(self, dindex, nam_off, nam_part, nam_x, nam_y, reads, read_off, upload_only=False):
         """Device-planned batch (ultra_mam_stage_nams): the NAM chains and reads of the instances as flat arrays (the
-        fields of ultra_plan_request); candidates and pairs are produced on the GPU over the resident index."""
+        fields of ultra_plan_request); candidates and pairs are produced on the GPU over the resident index.
+        upload_only: only the copy to the device (ultra_mam_upload_nams); mam_plan_resident() plans from it."""
         a_off = _arr(nam_off, np.int64); a_part = _arr(nam_part, np.int64).ravel()
         a_x = _arr(nam_x, np.int64); a_y = _arr(nam_y, np.int64)
         a_reads = _arr(reads, np.uint8); a_roff = _arr(read_off, np.int64)
@@ -352,7 +356,15 @@ class Context(object):
         rq.nam_x = _ptr(a_x, C.c_int64); rq.nam_y = _ptr(a_y, C.c_int64)
         rq.reads = _ptr(a_reads, C.c_uint8); rq.read_off = _ptr(a_roff, C.c_int64)
         self._mam_n_inst = n_inst
+        if upload_only:
+            self._check(self.lib.ultra_mam_upload_nams(self._h, C.byref(rq)))
+            return
         self._check(self.lib.ultra_mam_stage_nams(self._h, dindex.handle, C.byref(rq)))
+        self._staged_n = self.mam_counts()[2]
+
+    def mam_plan_resident(self, dindex):
+        """Plans and stages the uploaded request again, from HBM (ultra_mam_plan_resident)."""
+        self._check(self.lib.ultra_mam_plan_resident(self._h, dindex.handle))
         self._staged_n = self.mam_counts()[2]
 
     def mam_counts(self):

@@ -76,6 +76,8 @@ def file_IO(input_queue, reads, seeds, output_sam_buffer, outfile_name):
 
 def _consumer(process_id, device, input_queue, output_sam_buffer, counts_queue, args):
     os.environ["LOCAL_RANK"] = str(device)      # before anything touches HIP in this process
+    from . import hwq
+    hwq.export_hw_queues()                      # a spawned child: HIP is not up yet; one hardware queue per launch lane, as benched
     from . import align
     align.align_single(process_id, input_queue, output_sam_buffer, counts_queue, args)
 
@@ -103,10 +105,18 @@ def main(reads, seeds, outfile, args):
         w.start()
     for w in workers:
         w.join()
-    producer.join()
+    # Exit codes first: with every consumer dead the producer blocks forever on the 200-slot input queue, and joining it
+    # would hang the run instead of reporting the failure.  One dead consumer is an error too (its batches are lost).
     failed = [w.exitcode for w in workers if w.exitcode != 0]
     if failed:
+        producer.terminate()
+        producer.join()
+        manager.shutdown()
         raise RuntimeError("ultra_amd.pc.main: a GPU worker ended with exit code %r" % failed[0])
+    producer.join()
+    if producer.exitcode != 0:
+        manager.shutdown()
+        raise RuntimeError("ultra_amd.pc.main: the file_IO producer ended with exit code %r" % producer.exitcode)
     with open(outfile, "a") as fh:
         _drain(fh, output_sam_buffer)
     tot_counts = [0, 0, 0, 0, 0, 0, 0, 0]

@@ -39,7 +39,7 @@ PRESETS = {
 WORLDS = {
     "small": dict(n_genes=1500, n_chr=8),
     "c2": dict(n_genes=900, n_chr=1, exon_mean=12.0, max_exons=60, split_frac=0.45, overlap_frac=0.15),
-    "c3": dict(n_genes=60000, n_chr=24, exon_mean=12.0, max_exons=60, split_frac=0.45, overlap_frac=0.15),
+    "c3": dict(n_genes=60000, n_chr=24, exon_mean=12.0, max_exons=60, split_frac=0.45, overlap_frac=0.15, tr_max=7),  # ~240 k transcripts
 }
 
 
@@ -72,7 +72,7 @@ def _rand_seq(rng, n):
 
 
 def make_world(seed=20241008, n_genes=200, n_chr=2, flank=1000, small_thr=200, max_exons=30,
-               small_exon_frac=0.03, split_frac=0.3, exon_mean=9.0, overlap_frac=0.0):
+               small_exon_frac=0.03, split_frac=0.3, exon_mean=9.0, overlap_frac=0.0, tr_max=4):
     """overlap_frac: share of genes that overlap the previous gene of their chromosome - they reuse a run of its
     exon parts (same coordinates, so the shared segments belong to both genes) and add exons of their own behind it."""
     rng = np.random.RandomState(seed)
@@ -142,7 +142,7 @@ def make_world(seed=20241008, n_genes=200, n_chr=2, flank=1000, small_thr=200, m
             fs = _rand_seq(rng, f[2] - f[1])
             w.part_seq[f] = fs
             w.ref_flank_sequences[key_of(*f)] = fs
-        n_tr = int(rng.randint(1, 5))
+        n_tr = int(rng.randint(1, tr_max + 1))
         for t in range(n_tr):
             if t == 0 or n_ex <= 2:
                 chosen = list(exons)
