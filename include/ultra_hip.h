@@ -407,6 +407,74 @@ int ultra_pipe_wait(ultra_pipe *pipe, int32_t *n_inst, int64_t *n_chain, ultra_m
 int ultra_pipe_release(ultra_pipe *pipe);
 int ultra_pipe_timing(const ultra_pipe *pipe, float ms[4], double *cells, float myers_ms[5], float mam_ms[3]);
 
+/*
+ * The per-read steps in FRONT of the MAM stage for a whole batch of reads, natively (worker threads on the host, one
+ * NAM-chaining launch and one device-planned MAM stage on the GPU).  Replaces, per read of the batch,
+ *     get_mems_from_input                  modules/align.py:357-388   hit lines -> NAMs per chromosome sorted by y
+ *     annotate_guaranteed_optimal_bound    modules/align.py:112-188   instances cut at the intron limit + coverage bound
+ *     the chaining loop of align_single    modules/align.py:440-475   instances by descending bound, break rule (:443),
+ *                                                                     solver switch (:448), every co-optimal chain,
+ *                                                                     sort by (-score, span), dropoff / max_loc (:472)
+ *     help_functions.remove_read_polyA_ends (:41-73, the sequence; to_len = 1 as align.py:431 calls it)
+ *     help_functions.reverse_complement     (:93-97) for locations on the reverse strand
+ * and then classify_read_with_mams.main for every kept (read, location) (ultra_mam_stage_nams / _run / _fetch above).
+ *
+ * Input: the raw reads, and the hit lines of every read as byte ranges of one text block in the format namfinder
+ * writes ("<chr^start^stop> <ref_pos> <read_pos> <len>" per line, whitespace separated, 1-based positions;
+ * modules/seed_wrapper.py:139-179 streams these lines): fw_* = the read's forward record, rc_* = its "Reverse" record.
+ * max_intron_chr is indexed by chromosome id (-1 = no entry: the reference's KeyError).  What the reference answers
+ * with a Python exception (a malformed hit line, an unknown chromosome) is ULTRA_E_ARG with the read's index in the
+ * text of ultra_front_last_error.
+ *
+ * Output (ultra_front_view: pointers into memory the ultra_front owns, valid until its next call or destruction):
+ *   read_mod / read_mod_off      the poly-A-trimmed reads
+ *   loc_off[n_reads + 1]         the locations kept per read, in the reference's order; per location its chromosome,
+ *                                strand, NAM-chaining score, NAM chain (sol_*: CSR by sol_off; part = 3 values per NAM)
+ *                                and the read as the MAM stage saw it (loc_reads: reverse-complemented where loc_rc)
+ *   last_limit[n_reads]          the intron limit of the last instance the chaining loop worked on (:446; -1 = none),
+ *                                which the reference's later filter (:505) compares every location of the read with
+ *   mam                          the MAM stage's results, one instance per location (chain_kind / chain_chr included)
+ *   ms[6]                        host milliseconds: parse + bounds, NAM chaining, selection, stage, run, fetch
+ * ultra_front_prepare stops after the first phase (no GPU): instances in processing order (read_inst_off, their NAMs as
+ * inst_nam_off / nam_y / nam_c / nam_d / inst_intron, and four values per instance - chromosome, strand, bound, read -
+ * in inst_chr_rc_bound) for parity tests on machines without a GPU.
+ */
+typedef struct ultra_front ultra_front;
+typedef struct ultra_front_input {
+    int32_t n_reads;
+    const uint8_t *reads; const int64_t *read_off;
+    const uint8_t *seed_text;
+    const int64_t *fw_begin, *fw_end, *rc_begin, *rc_end;
+    int32_t n_chr; const int64_t *max_intron_chr;
+    int64_t max_global_intron;     /* args.max_intron */
+    double dropoff;                /* args.dropoff */
+    int32_t max_loc;               /* args.max_loc */
+    int32_t polyA_threshold;       /* args.reduce_read_ployA */
+    double min_acc;                /* args.min_acc */
+    int32_t n_threads;             /* 0 = min(16, hardware threads) */
+} ultra_front_input;
+typedef struct ultra_front_view {
+    int64_t n_inst; const int64_t *read_inst_off;
+    int64_t n_nam; const int64_t *inst_nam_off, *inst_intron; const int32_t *nam_y, *nam_c, *nam_d;
+    const int64_t *inst_chr_rc_bound;
+    const uint8_t *read_mod; const int64_t *read_mod_off;
+    int64_t n_loc; const int64_t *loc_off, *last_limit;
+    const int32_t *loc_chr; const uint8_t *loc_rc; const int64_t *loc_score;
+    const int64_t *sol_off, *sol_part, *sol_x, *sol_y; const int32_t *sol_c, *sol_d, *sol_j; /* sol_j: the seed's index in its instance (Mem.j) */
+    const uint8_t *loc_reads; const int64_t *loc_read_off;
+    int64_t n_quadratic, n_nlogn;  /* instances that took the quadratic / the n log n NAM solver (align.py:450, :453) */
+    ultra_mam_output mam;
+    float ms[6];
+} ultra_front_view;
+int ultra_front_create(ultra_front **out);
+void ultra_front_destroy(ultra_front *f);
+const char *ultra_front_last_error(const ultra_front *f);
+int ultra_front_prepare(ultra_front *f, const ultra_front_input *in, ultra_front_view *view);
+/* ix: the host index, for batches beyond the device planner's envelope (may be NULL: such a batch is ULTRA_E_UNSUPPORTED);
+ * with_mam_stage = 0 stops after the location selection (dix may then be NULL) */
+int ultra_front_run(ultra_front *f, ultra_ctx *ctx, const ultra_dindex *dix, const ultra_index *ix, const ultra_front_input *in,
+                    int32_t with_mam_stage, ultra_front_view *view);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,7 +169,8 @@ def test_one_read_outside_the_envelope_does_not_take_the_batch_down(ctx, tmp_pat
     records = [["read%d" % i, read, None, [seed_wrapper.format_hit(m) for m in sol], []] for i, (read, sol, _) in enumerate(sims)]
     # the long read: 40 kb of the exon with a few edits, seeds = its exact stretches (one NAM per 500 bases is plenty)
     from tests import helpers
-    long_read = helpers.mutate(rng, big_seq[5000:45000], 0.01)
+    # (substitutions only, from the exon's first base: the stub base-level alignment of this test compares position by position)
+    long_read = helpers.mutate(rng, big_seq[:40000], 0.01, mix=(0.0, 1.0, 0.0))
     hits = []
     for c in range(0, len(long_read) - 40, 2000):
         piece = long_read[c:c + 25]

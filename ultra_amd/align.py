@@ -384,6 +384,10 @@ class AlignState(object):
             self.notes.append("device planner not usable for this index (%s): batches are planned on the host" % e)
         self._parts = {}
         self.n_quadratic = self.n_nlogn = 0
+        from . import front as _front
+        # phases 1-4 of align_reads_batch natively (csrc/front.hip); without a device index the batch's MAM stage is
+        # planned on the host inside mam_stage() below
+        self.front = _front.Front(self.ctx, self.dindex, self.native, self.max_intron_chr)
 
     def five(self):
         return (self.ref_segment_sequences, self.ref_flank_sequences, self.parts_to_segments, self.segment_to_gene,
@@ -409,6 +413,7 @@ class AlignState(object):
         return classify_read_with_mams.main_batch(instances, *self.five(), min_acc=min_acc, ctx=self.ctx, index=self.native)
 
     def close(self):
+        self.front.close()
         if self.dindex is not None:
             self.dindex.close()
         self.native.close()
@@ -420,27 +425,31 @@ def align_reads_batch(records, state, args, downstream):
     for these reads."""
     n = len(records)
     counts = [0] * 8
-    mods = [remove_read_polyA_ends(seq, qual, args.reduce_read_ployA, 1) for _, seq, qual, _, _ in records]
-    # ---- phases 1-3: seeds -> instances -> NAM chaining -> location selection ----
-    intron_limit = []
-    locations = chain_reads_batch([(hits, hits_rc) for _, _, _, hits, hits_rc in records], state.max_intron_chr,
-                                  args.max_intron, args.dropoff, args.max_loc, ctx=state.ctx, last_limits=intron_limit)
-    # ---- phase 4: one MAM stage over every (read, location) ----
-    instances, owner = [], []
+    # ---- phases 1-4, natively for the whole batch (csrc/front.hip): hit lines -> instances + bounds -> ONE NAM chaining
+    #      launch -> location selection -> ONE MAM stage over every (read, location); poly-A trimming and reverse
+    #      complements of the reads included.  Python objects are made below for what the later phases touch. ----
+    from . import front as _front
+    fr = state.front.run(_front.PackedBatch.from_records(records), args.max_intron, args.dropoff, args.max_loc, args.reduce_read_ployA,
+                         args.min_acc, with_mam_stage=state.dindex is not None)
+    state.n_quadratic += fr.n_quadratic; state.n_nlogn += fr.n_nlogn
+    loc_off = fr.loc_off.tolist()
+    loc_chr, loc_rc, loc_score = fr.loc_chr.tolist(), fr.loc_rc.tolist(), fr.loc_score.tolist()
+    intron_limit = [None if v < 0 else v for v in fr.last_limit.tolist()]
+    mods = []
+    for r, (_, seq, qual, _, _) in enumerate(records):
+        mods.append((fr.read_mod_seq(r), None if qual is None else remove_read_polyA_ends(seq, qual, args.reduce_read_ployA, 1)[1]))
+    if state.dindex is not None:
+        mam_of = fr.mam
+    else:       # an index the device planner cannot hold: the MAM stage of the batch planned on the host
+        host = state.mam_stage([(fr.solution(l), fr.loc_read_seq(l)) for l in range(fr.n_loc)], args.min_acc)
+        mam_of = host.__getitem__
+    locations = [[(loc_chr[l], None, loc_score[l], bool(loc_rc[l])) for l in range(loc_off[r], loc_off[r + 1])] for r in range(n)]
+    by_read = [[mam_of(l) for l in range(loc_off[r], loc_off[r + 1])] for r in range(n)]
     rc_cache = {}
-    for r, locs in enumerate(locations):
-        for li, (chr_id, sol, score, is_rc) in enumerate(locs):
-            if is_rc:
-                if r not in rc_cache:
-                    rc_cache[r] = reverse_complement(mods[r][0])
-                instances.append((sol, rc_cache[r]))
-            else:
-                instances.append((sol, mods[r][0]))
-            owner.append((r, li))
-    mam_results = state.mam_stage(instances, args.min_acc)
-    by_read = [[] for _ in range(n)]
-    for (r, li), res in zip(owner, mam_results):
-        by_read[r].append(res)
+    for r in range(n):
+        for l in range(loc_off[r], loc_off[r + 1]):
+            if loc_rc[l] and r not in rc_cache:
+                rc_cache[r] = fr.loc_read_seq(l)
     # ---- phase 5: exon reconstruction + classification per surviving location; alignment jobs collected ----
     pending = []        # per read: [(location fields..., job index)]
     jobs = []

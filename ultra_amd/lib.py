@@ -30,6 +30,7 @@ EXPORTS = [
     "ultra_mam_fetch_plan",
     "ultra_pipe_create", "ultra_pipe_destroy", "ultra_pipe_last_error", "ultra_pipe_submit", "ultra_pipe_pending",
     "ultra_pipe_wait", "ultra_pipe_release", "ultra_pipe_timing", "ultra_sg_affine_batch",
+    "ultra_front_create", "ultra_front_destroy", "ultra_front_last_error", "ultra_front_prepare", "ultra_front_run",
 ]
 
 
@@ -82,6 +83,28 @@ class PlanRequest(C.Structure):
     """ultra_plan_request (include/ultra_hip.h)."""
     _fields_ = [("n_inst", C.c_int32), ("inst_nam_off", _I64P), ("nam_part", _I64P), ("nam_x", _I64P), ("nam_y", _I64P),
                 ("reads", _U8P), ("read_off", _I64P)]
+
+
+class FrontInput(C.Structure):
+    """ultra_front_input (include/ultra_hip.h)."""
+    _fields_ = [("n_reads", C.c_int32), ("reads", _U8P), ("read_off", _I64P), ("seed_text", _U8P),
+                ("fw_begin", _I64P), ("fw_end", _I64P), ("rc_begin", _I64P), ("rc_end", _I64P),
+                ("n_chr", C.c_int32), ("max_intron_chr", _I64P), ("max_global_intron", C.c_int64), ("dropoff", C.c_double),
+                ("max_loc", C.c_int32), ("polyA_threshold", C.c_int32), ("min_acc", C.c_double), ("n_threads", C.c_int32)]
+
+
+class FrontView(C.Structure):
+    """ultra_front_view (include/ultra_hip.h)."""
+    _fields_ = [("n_inst", C.c_int64), ("read_inst_off", _I64P),
+                ("n_nam", C.c_int64), ("inst_nam_off", _I64P), ("inst_intron", _I64P), ("nam_y", _I32P), ("nam_c", _I32P), ("nam_d", _I32P),
+                ("inst_chr_rc_bound", _I64P),
+                ("read_mod", _U8P), ("read_mod_off", _I64P),
+                ("n_loc", C.c_int64), ("loc_off", _I64P), ("last_limit", _I64P),
+                ("loc_chr", _I32P), ("loc_rc", _U8P), ("loc_score", _I64P),
+                ("sol_off", _I64P), ("sol_part", _I64P), ("sol_x", _I64P), ("sol_y", _I64P), ("sol_c", _I32P), ("sol_d", _I32P), ("sol_j", _I32P),
+                ("loc_reads", _U8P), ("loc_read_off", _I64P),
+                ("n_quadratic", C.c_int64), ("n_nlogn", C.c_int64),
+                ("mam", MamOutput), ("ms", C.c_float * 6)]
 
 
 _lib = None
@@ -164,6 +187,13 @@ def load():
     lib.ultra_pipe_wait.argtypes = [vp, i32p, i64p, C.POINTER(MamOutput)]
     lib.ultra_pipe_release.argtypes = [vp]
     lib.ultra_pipe_timing.argtypes = [vp, C.POINTER(C.c_float), f64p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.ultra_front_create.argtypes = [C.POINTER(vp)]
+    lib.ultra_front_destroy.argtypes = [vp]
+    lib.ultra_front_destroy.restype = None
+    lib.ultra_front_last_error.argtypes = [vp]
+    lib.ultra_front_last_error.restype = C.c_char_p
+    lib.ultra_front_prepare.argtypes = [vp, C.POINTER(FrontInput), C.POINTER(FrontView)]
+    lib.ultra_front_run.argtypes = [vp, vp, vp, vp, C.POINTER(FrontInput), C.c_int32, C.POINTER(FrontView)]
     _lib = lib
     return lib
 
