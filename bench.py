@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (0 = skip)")
     ap.add_argument("--e2e-rounds", type=int, default=4, help="passes over the batches through ultra_pipe (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight in the end-to-end leg")
+    ap.add_argument("--front-rounds", type=int, default=2, help="passes over two batches through the native front end (0 = skip)")
     ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
     ap.add_argument("--micro-scale", type=float, default=1.0, help="fraction of the micro-benchmarks' pair counts")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (default 16)")
@@ -348,6 +349,54 @@ def main():
                "chain_rows_fetched": chains,
                "synchronous_caller_reads_per_s": args.reads / ((restage_ms + run_max / K * 1e3 + fetch_s * 1e3) * 1e-3)}
 
+    # ---- the per-read host steps in front of the MAM stage (align.py:427-489), natively: seed text -> SAM-ready arrays ----
+    front_leg = None
+    if rank == 0 and args.front_rounds > 0:
+        from ultra_amd import front as front_mod
+        fr = front_mod.Front(ctxs[0], dix, nix, {c: 200000 for c in range(wkw["n_chr"])})
+        pbs = []
+        for rs in sets[:2]:
+            text, line_off = synth.seed_text(rs)
+            none = np.zeros(len(rs), np.int64)
+            pbs.append(front_mod.PackedBatch(rs.reads, rs.read_off, text, line_off[:-1], line_off[1:], none, none))
+        prm = (1200000, 0.95, 5, 8, P["min_acc"])       # uLTRA's defaults: --max_intron, --dropoff, --max_loc, --reduce_read_ployA
+        fr.run(pbs[0], *prm, copy=False)
+        t0 = time.perf_counter()
+        ms_acc, n_loc = [0.0] * 6, 0
+        for _ in range(args.front_rounds):
+            for pb in pbs:
+                r = fr.run(pb, *prm, copy=False)
+                n_loc += r["n_loc"]
+                ms_acc = [a + b for a, b in zip(ms_acc, r["ms"])]
+        secs = time.perf_counter() - t0
+        n_calls = args.front_rounds * len(pbs)
+        t0 = time.perf_counter()
+        res = fr.run(pbs[0], *prm)                       # the same with every array copied out into numpy
+        numpy_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        n_t = min(res.n_loc, 20000)
+        for l in range(n_t):
+            res.mam(l)
+        tuple_us = (time.perf_counter() - t0) / max(n_t, 1) * 1e6
+        # the Python shims this replaces, on a sample (they are the reference-shaped per-read loop)
+        from ultra_amd import align as align_mod
+        n_py = 2000
+        hits = [(pbs[0].text[int(pbs[0].fw_begin[i]):int(pbs[0].fw_end[i])].tobytes().decode().splitlines(True), []) for i in range(n_py)]
+        t0 = time.perf_counter()
+        align_mod.chain_reads_batch(hits, {c: 200000 for c in range(wkw["n_chr"])}, 1200000, 0.95, 5, ctx=ctxs[0])
+        py_us = (time.perf_counter() - t0) / n_py * 1e6
+        front_leg = {"align_single_front_reads_per_s": args.reads * n_calls / secs,
+                     "what": "ultra_front_run per batch of %d reads: hit lines (text, %.0f bytes per read) + raw reads -> instances and bounds "
+                             "-> one NAM chaining launch -> location selection -> device-planned MAM stage -> results in host arrays; "
+                             "align.py:427-489 for the whole batch, one process, %d host threads"
+                             % (args.reads, pbs[0].text.size / float(args.reads), min(16, len(os.sched_getaffinity(0)))),
+                     "ms_per_batch": {k: v / n_calls for k, v in zip(("parse_bounds", "nam_chaining", "selection", "stage", "run", "fetch"), ms_acc)},
+                     "locations_per_read": n_loc / float(args.reads * n_calls),
+                     "with_numpy_copies_reads_per_s": args.reads / numpy_s,
+                     "python_tuple_us_per_location_on_access": tuple_us,
+                     "python_shims_us_per_read_phases_1_to_3": py_us}
+        fr.close()
+
     micro = None
     if rank == 0 and args.micro:
         peak_tops = info["n_cu"] * LANES_PER_CU_CLK * PEAK_CLOCK_GHZ * 1e9 * 1e-12
@@ -441,6 +490,7 @@ def main():
                                      "fetch_results_pcie_ms": fetch_s * 1e3, "python_tuples_ms": topy_s * 1e3,
                                      "world_s": world_s, "reads_s": reads_s, "host_index_s": index_s, "device_index_s": dindex_s},
             "end_to_end": e2e,
+            "front_end": front_leg,
             "forward_buckets": {"bucket%d_wmax%d" % k: {"cells_per_step": v[0] / v[2], "ms_per_step": v[1] / v[2],
                                                         "tcups": v[0] / v[1] * 1e-9 if v[1] > 0 else None}
                                 for k, v in sorted(class_ms.items())},

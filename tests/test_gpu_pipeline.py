@@ -176,7 +176,7 @@ def test_one_read_outside_the_envelope_does_not_take_the_batch_down(ctx, tmp_pat
         piece = long_read[c:c + 25]
         at = big_seq.find(piece)
         if at >= 0 and big_seq.find(piece, at + 1) < 0:
-            hits.append("%d^%d^%d\t%d\t%d\t%d" % (chr_id, big[1], big[2], at + 1, c + 1, 25))
+            hits.append("%d^%d^%d\t%d\t%d\t%d\n" % (chr_id, big[1], big[2], at + 1, c + 1, 25))
     assert len(hits) > 10
     long_rec = ["long_read", long_read, None, hits, []]
     # the read no batch can hold: its own 40 distinct bytes on top of the index's

@@ -322,4 +322,38 @@ void synth_pairs_copy(const synth_pairs_out *o, uint8_t *arena, int64_t *q_off, 
 
 void synth_pairs_free(synth_pairs_out *o) { delete o; }
 
+// The seed text namfinder would write for reads with these NAM chains (modules/seed_wrapper.py:139-179 format), as hit
+// lines only: read r's lines are text[line_off[r] .. line_off[r + 1]).  Returns the bytes written, or the bytes needed
+// (negative) when cap is too small.
+int64_t synth_seed_text(int64_t n_reads, const int64_t *nam_off, const int64_t *nam_part, const int64_t *nam_x, const int64_t *nam_y,
+                        const int64_t *nam_c, uint8_t *text, int64_t cap, int64_t *line_off)
+{
+    auto put = [](uint8_t *at, int64_t v) {
+        char tmp[24]; int n = 0;
+        if (v == 0) tmp[n++] = '0';
+        bool neg = v < 0; if (neg) v = -v;
+        while (v > 0) { tmp[n++] = (char)('0' + v % 10); v /= 10; }
+        int w = 0;
+        if (neg) at[w++] = '-';
+        while (n > 0) at[w++] = (uint8_t)tmp[--n];
+        return w;
+    };
+    const int64_t need = nam_off[n_reads] * 100;
+    if (need > cap) return -need;
+    int64_t at = 0;
+    for (int64_t r = 0; r < n_reads; r++) {
+        line_off[r] = at;
+        for (int64_t u = nam_off[r]; u < nam_off[r + 1]; u++) {
+            at += put(text + at, nam_part[3 * u]); text[at++] = '^';
+            at += put(text + at, nam_part[3 * u + 1]); text[at++] = '^';
+            at += put(text + at, nam_part[3 * u + 2]); text[at++] = '\t';
+            at += put(text + at, nam_x[u] - nam_part[3 * u + 1] + 1); text[at++] = '\t';
+            at += put(text + at, nam_c[u] + 1); text[at++] = '\t';
+            at += put(text + at, nam_y[u] - nam_x[u] + 1); text[at++] = '\n';
+        }
+    }
+    line_off[n_reads] = at;
+    return at;
+}
+
 } // extern "C"

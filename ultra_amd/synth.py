@@ -333,6 +333,8 @@ def _synth_lib():
         lib.synth_pairs_copy.restype = None
         lib.synth_pairs_free.argtypes = [_C.c_void_p]
         lib.synth_pairs_free.restype = None
+        lib.synth_seed_text.argtypes = [_C.c_int64] + [_C.c_void_p] * 6 + [_C.c_int64, _C.c_void_p]
+        lib.synth_seed_text.restype = _C.c_int64
         _SYNTH_LIB = lib
     return _SYNTH_LIB
 
@@ -393,6 +395,21 @@ class ReadSet(object):
             x, y, c, d = int(self.nam_x[u]), int(self.nam_y[u]), int(self.nam_c[u]), int(self.nam_d[u])
             sol.append(Mem(x, y, c, d, y - x + 1, j, pid))
         return self.reads[r0:r1].tobytes().decode(), sol, int(self.chr[i])
+
+
+def seed_text(rs):
+    """(text uint8, line_off int64[n + 1]): the hit lines a seeder would write for the NAM chains of ReadSet rs - read r's
+    forward record is text[line_off[r]:line_off[r + 1]] (the format of seed_wrapper.read_seeds)."""
+    n = len(rs)
+    cap = int(rs.nam_off[-1]) * 100 + 16
+    text = np.empty(cap, np.uint8)
+    line_off = np.zeros(n + 1, np.int64)
+    a = [np.ascontiguousarray(v, np.int64) for v in (rs.nam_off, rs.nam_part, rs.nam_x, rs.nam_y, rs.nam_c)]
+    got = _synth_lib().synth_seed_text(n, *[v.ctypes.data_as(_C.c_void_p) for v in a], text.ctypes.data_as(_C.c_void_p), cap,
+                                       line_off.ctypes.data_as(_C.c_void_p))
+    if got < 0:
+        raise RuntimeError("synth_seed_text: buffer too small")
+    return text[:max(got, 1)], line_off
 
 
 def make_reads_native(flat, n, seed=1, preset="ont_cdna", min_nam=15, flank_start_prob=0.15, flank_end_prob=0.1, threads=0):
