@@ -74,6 +74,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (0 = skip)")
     ap.add_argument("--e2e-rounds", type=int, default=4, help="passes over the batches through ultra_pipe (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight in the end-to-end leg")
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="host threads of the timed loop: 2 = the enumeration of the next batch rides beside the kernels of the current "
+                         "one (two contexts, runs serialised), 1 = plan and run one after the other")
     ap.add_argument("--front-rounds", type=int, default=2, help="passes over two batches through the native front end (0 = skip)")
     ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
     ap.add_argument("--micro-scale", type=float, default=1.0, help="fraction of the micro-benchmarks' pair counts")
@@ -240,30 +243,53 @@ def main():
     ctxs[0].mam_run(P["min_acc"])
     class_ms = {}
     acc = {"fwd": 0.0, "rev": 0.0, "tb": 0.0, "all": 0.0, "fwdk": 0.0, "build": 0.0, "chain": 0.0, "gather": 0.0}
-    cells_run = cells_skip = pairs_skip = 0.0
-    plan_s = run_s = 0.0
+    import threading
+    tot = {"cells_run": 0.0, "cells_skip": 0.0, "pairs_skip": 0.0, "plan_s": 0.0, "run_s": 0.0}
+    run_lock = threading.Lock()      # a run fills the chip: one at a time; the other thread's enumeration rides beside it
+    n_thr = max(1, min(args.overlap, nb))
+    errors = []
+
+    def steps_of(tid):
+        try:
+            for i in range(tid, args.steps, n_thr):     # step i works on context i % nb: never shared between the threads (nb % n_thr == 0)
+                c = ctxs[i % nb]
+                t1 = time.perf_counter()
+                c.mam_plan_resident(dix)    # a4's enumeration, pair sort, work lists: from the request resident in HBM
+                t2 = time.perf_counter()
+                with run_lock:
+                    t3 = time.perf_counter()
+                    c.mam_run(P["min_acc"])
+                    tot["run_s"] += time.perf_counter() - t3
+                    tot["plan_s"] += t2 - t1
+                    cells, ms = c.myers_timing()
+                    tot["cells_run"] += cells
+                    sk = c.myers_cell_counts()
+                    tot["cells_skip"] += sk[1]; tot["pairs_skip"] += sk[2]
+                    acc["fwd"] += ms[0]; acc["rev"] += ms[1]; acc["tb"] += ms[2]; acc["all"] += ms[3]; acc["fwdk"] += ms[4]
+                    mm = c.mam_timing()
+                    acc["build"] += mm[0]; acc["chain"] += mm[1]; acc["gather"] += mm[2]
+                    for key, (cc, t) in c.myers_class_timing().items():
+                        a = class_ms.setdefault(key, [0.0, 0.0, 0])
+                        a[0] += cc; a[1] += t; a[2] += 1
+        except Exception as e:      # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+    if nb % n_thr:
+        n_thr = 1
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        c = ctxs[i % nb]
-        t1 = time.perf_counter()
-        c.mam_plan_resident(dix)        # a4's enumeration, pair sort, work lists: from the request resident in HBM
-        t2 = time.perf_counter()
-        c.mam_run(P["min_acc"])
-        run_s += time.perf_counter() - t2
-        plan_s += t2 - t1
-        cells, ms = c.myers_timing()
-        cells_run += cells
-        sk = c.myers_cell_counts()
-        cells_skip += sk[1]; pairs_skip += sk[2]
-        acc["fwd"] += ms[0]; acc["rev"] += ms[1]; acc["tb"] += ms[2]; acc["all"] += ms[3]; acc["fwdk"] += ms[4]
-        mm = c.mam_timing()
-        acc["build"] += mm[0]; acc["chain"] += mm[1]; acc["gather"] += mm[2]
-        for key, (cc, t) in c.myers_class_timing().items():
-            a = class_ms.setdefault(key, [0.0, 0.0, 0])
-            a[0] += cc; a[1] += t; a[2] += 1
+    if n_thr == 1:
+        steps_of(0)
+    else:
+        ths = [threading.Thread(target=steps_of, args=(t,)) for t in range(n_thr)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
     barrier()
     elapsed = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
+    cells_run, cells_skip, pairs_skip, plan_s, run_s = (tot[k] for k in ("cells_run", "cells_skip", "pairs_skip", "plan_s", "run_s"))
     K = args.steps
     elapsed, reads_all, cells_all = shard.reduce_job(elapsed, args.reads * K, cells_run, device=red_dev)
     run_max, _, cells_skip_all = shard.reduce_job(run_s, 0, cells_skip, device=red_dev)
@@ -482,6 +508,10 @@ def main():
             "kernels_only": {"reads_per_s": reads_all / run_max, "ms_per_step": run_max / K * 1e3,
                              "note": "ultra_mam_run alone (candidates and sorted pairs already staged): what round 2 reported as value"},
             "plan_ms_per_step": plan_s / K * 1e3,
+            "host_threads": n_thr,
+            "overlap_note": "with 2 host threads the enumeration + pair sort of batch i + 1 (its own context) runs beside the kernels of "
+                            "batch i; runs are serialised.  ms_per_step = wall time / steps; plan_ms_per_step and kernels_only are the two "
+                            "parts as their threads saw them (they overlap, so they add up to more than ms_per_step)",
             "stage_ms_per_step": {"myers_forward": acc["fwd"] / K, "myers_starts": acc["rev"] / K, "myers_traceback": acc["tb"] / K,
                                   "myers_total": acc["all"] / K, "mam_build": acc["build"] / K, "chain": acc["chain"] / K,
                                   "chain_gather": acc["gather"] / K},

@@ -65,7 +65,7 @@ def test_noalloc_allocates_no_device_memory(ctx):
     warm = _batch(rng, [4, 30], [100])
     ctx.chain_mams_batch(*warm, noalloc=True)               # module load, first use of the streams
     before = _free_device_bytes()
-    sizes = [int(s) for s in rng.choice([1, 9, 48, 49, 199, 201, 450, 900, 2500], size=400)]
+    sizes = [int(s) for s in rng.choice([1, 9, 48, 49, 199, 201, 450, 900, 2500], size=120)]
     batch = _batch(rng, sizes, [300, 3000])
     for kw in (dict(solver=0), dict(solver=2), dict(solver=1)):
         ctx.chain_mams_batch(*batch, noalloc=True, **kw)
