@@ -25,18 +25,39 @@
 
 namespace {
 
-struct Nam { int64_t x, y; int32_t c, d; int64_t p0, p1; int32_t chr; };
+struct Nam { int32_t x, y, c, d, p0, p1, chr; };
 struct Inst { int64_t first; int32_t n; int32_t chr; int32_t read; uint8_t rc; int64_t bound; int64_t limit; };
-struct Loc { int32_t read, chr; uint8_t rc; int64_t score; int64_t sol_first; int32_t sol_n; int64_t inst_first; };
+struct Loc { int32_t read, chr; uint8_t rc; int64_t score; const int64_t *sol; int32_t sol_n; int64_t inst_first; };
 
-struct Part { // what one worker thread produced for its range of reads (concatenated in read order afterwards)
-    std::vector<Nam> nams;
-    std::vector<Inst> insts;
+// bytes that are written right after they are reserved: no value-initialisation as std::vector::resize would do
+struct RawBytes {
+    uint8_t *p = nullptr; size_t cap = 0, n = 0;
+    RawBytes() = default;
+    RawBytes(const RawBytes &) = delete;
+    RawBytes &operator=(const RawBytes &) = delete;
+    RawBytes(RawBytes &&o) noexcept : p(o.p), cap(o.cap), n(o.n) { o.p = nullptr; o.cap = o.n = 0; }
+    ~RawBytes() { free(p); }
+    uint8_t *room(size_t more)
+    {
+        if (n + more > cap) { cap = (n + more) * 2 + 4096; p = (uint8_t *)realloc(p, cap); }
+        return p + n;
+    }
+};
+
+struct Part { // what one worker thread produced for its range of reads (copied to its place in read order afterwards)
+    std::vector<Nam> nams;          // instance after instance, in the read's processing order
+    std::vector<Inst> insts;        // first = position in this part's nams
     std::vector<int32_t> inst_per_read;
-    std::vector<uint8_t> mod;       // poly-A-trimmed reads
+    RawBytes mod;                   // poly-A-trimmed reads
     std::vector<int64_t> mod_len;
     std::string err;
     int err_read = -1;
+    void reset() { nams.clear(); insts.clear(); inst_per_read.clear(); mod.n = 0; mod_len.clear(); err.clear(); err_read = -1; }
+};
+// selection phase, per worker thread
+struct SelPart {
+    std::vector<Loc> locs; std::vector<int32_t> per_read; std::vector<int64_t> sol; std::vector<int64_t> limit; int64_t nq = 0, nl = 0;
+    void reset() { locs.clear(); per_read.clear(); sol.clear(); limit.clear(); nq = nl = 0; }
 };
 
 inline bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); } // str.split() on ASCII
@@ -57,11 +78,27 @@ bool parse_int(const uint8_t *b, const uint8_t *e, int64_t &out)
     return true;
 }
 
-// one strand's hit lines [b, e) -> NAMs grouped by chromosome in order of first appearance, each group sorted by y (stable)
-bool parse_hits(const uint8_t *b, const uint8_t *e, std::vector<Nam> &out, std::vector<std::pair<int32_t, int32_t>> &groups, std::string &err)
+// stable; insertion sort for the short lists a read has (std::stable_sort allocates a buffer per call)
+template <typename T, typename Less> void stable_small_sort(T *b, T *e, Less less)
 {
-    std::vector<Nam> raw;
-    std::vector<int32_t> chr_order;
+    if (e - b > 48) { std::stable_sort(b, e, less); return; }
+    for (T *i = b + 1; i < e; i++) {
+        if (!less(*i, *(i - 1))) continue;
+        T v = *i;
+        T *j = i;
+        while (j > b && less(v, *(j - 1))) { *j = *(j - 1); j--; }
+        *j = v;
+    }
+}
+
+// one strand's hit lines [b, e) -> NAMs grouped by chromosome in order of first appearance, each group sorted by y (stable)
+struct ParseScratch { std::vector<Nam> raw; std::vector<int32_t> chr_order; };
+bool parse_hits(const uint8_t *b, const uint8_t *e, std::vector<Nam> &out, std::vector<std::pair<int32_t, int32_t>> &groups, ParseScratch &S,
+                std::string &err)
+{
+    std::vector<Nam> &raw = S.raw;
+    std::vector<int32_t> &chr_order = S.chr_order;
+    raw.clear(); chr_order.clear();
     while (b < e) {
         const uint8_t *le = (const uint8_t *)memchr(b, '\n', (size_t)(e - b));
         if (!le) le = e;
@@ -86,19 +123,21 @@ bool parse_hits(const uint8_t *b, const uint8_t *e, std::vector<Nam> &out, std::
             !parse_int(tok[1][0], tok[1][1], rpos) || !parse_int(tok[2][0], tok[2][1], qpos) || !parse_int(tok[3][0], tok[3][1], len)) {
             err = "a hit line holds something that is not an integer (ValueError in align.py:368-374)"; return false;
         }
+        const int64_t x = p0 + (rpos - 1), y = x + len - 1, c = qpos - 1, d = c + len - 1;
+        const int64_t LIM = 0x7fffffff;
+        if (chr < 0 || chr > LIM || c < 0 || d < c || d >= (1 << 30) || x < 0 || y >= LIM || p0 < 0 || p0 > LIM || p1 < 0 || p1 > LIM) {
+            err = "hit coordinates outside the supported range (read positions < 2^30, reference positions < 2^31 - 1)"; return false;
+        }
         Nam n;
-        n.x = p0 + (rpos - 1); n.y = n.x + len - 1;
-        const int64_t c = qpos - 1, d = c + len - 1;
-        if (chr < 0 || chr > 0x7fffffff || c < 0 || d < c || d >= (1 << 30) || n.x < 0 || n.y >= 0x7fffffffLL) { err = "hit coordinates outside the supported range"; return false; }
-        n.c = (int32_t)c; n.d = (int32_t)d; n.p0 = p0; n.p1 = p1; n.chr = (int32_t)chr;
+        n.x = (int32_t)x; n.y = (int32_t)y; n.c = (int32_t)c; n.d = (int32_t)d; n.p0 = (int32_t)p0; n.p1 = (int32_t)p1; n.chr = (int32_t)chr;
         raw.push_back(n);
-        if (std::find(chr_order.begin(), chr_order.end(), n.chr) == chr_order.end()) chr_order.push_back(n.chr);
+        if (chr_order.empty() || (chr_order.back() != n.chr && std::find(chr_order.begin(), chr_order.end(), n.chr) == chr_order.end())) chr_order.push_back(n.chr);
         b = le < e ? le + 1 : e;
     }
     for (int32_t chr : chr_order) {
         const int32_t first = (int32_t)out.size();
         for (const Nam &n : raw) if (n.chr == chr) out.push_back(n);
-        std::stable_sort(out.begin() + first, out.end(), [](const Nam &a, const Nam &b2) { return a.y < b2.y; });
+        stable_small_sort(out.data() + first, out.data() + out.size(), [](const Nam &a, const Nam &b2) { return a.y < b2.y; });
         groups.push_back({first, (int32_t)out.size() - first});
     }
     return true;
@@ -108,8 +147,12 @@ bool parse_hits(const uint8_t *b, const uint8_t *e, std::vector<Nam> &out, std::
 int64_t covered(const Nam *n, int32_t cnt, std::vector<std::pair<int32_t, int32_t>> &tmp)
 {
     tmp.clear();
-    for (int32_t i = 0; i < cnt; i++) tmp.push_back({n[i].c, n[i].d});
-    std::sort(tmp.begin(), tmp.end());
+    bool sorted = true;
+    for (int32_t i = 0; i < cnt; i++) {
+        tmp.push_back({n[i].c, n[i].d});
+        if (i > 0 && tmp[(size_t)i] < tmp[(size_t)i - 1]) sorted = false;
+    }
+    if (!sorted) stable_small_sort(tmp.data(), tmp.data() + tmp.size(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) { return a < b; });
     int64_t total = 0, end = -1;
     for (auto &iv : tmp)
         if (iv.second > end) { total += iv.second - std::max<int64_t>(iv.first, end + 1) + 1; end = iv.second; }
@@ -157,6 +200,11 @@ struct ultra_front {
     // phase 1
     std::vector<Nam> nams;
     std::vector<Inst> insts;
+    // worker-thread buffers live as long as the front: memory that is malloc'ed and touched for the first time in every batch
+    // costs more than the parsing itself (page faults of a multi-threaded process serialise in the kernel)
+    std::vector<Part> parts;
+    std::vector<SelPart> sel_parts;
+    size_t n_nam = 0, n_inst = 0, n_loc = 0; // the vectors below only grow (no re-initialisation per batch): these are the counts in use
     std::vector<int64_t> read_inst_off;     // instances of read r: [off[r], off[r + 1]) in the reference's processing order
     std::vector<uint8_t> mod;
     std::vector<int64_t> mod_off;
@@ -185,6 +233,8 @@ namespace {
 
 int front_fail(ultra_front *f, int code, const std::string &m) { f->err = m; return code; }
 
+template <typename V> void grow(V &v, size_t n) { if (v.size() < n) v.resize(n + n / 8 + 16); }
+
 int front_prepare(ultra_front *f, const ultra_front_input *in)
 {
     const int32_t n = in->n_reads;
@@ -192,30 +242,38 @@ int front_prepare(ultra_front *f, const ultra_front_input *in)
         (in->n_chr > 0 && !in->max_intron_chr))
         return front_fail(f, ULTRA_E_ARG, "ultra_front: null array or negative count");
     const int T = in->n_threads > 0 ? in->n_threads : (f->n_threads > 0 ? f->n_threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
-    std::vector<Part> parts((size_t)std::max(1, std::min<int>(T, std::max(n, 1))));
-    parallel_ranges(n, (int)parts.size(), [&](int t, int32_t rb, int32_t re) {
+    const int NP = std::max(1, std::min<int>(T, std::max(n, 1)));
+    std::vector<Part> &parts = f->parts;
+    if ((int)parts.size() < NP) parts.resize((size_t)NP);
+    for (auto &P : parts) P.reset();
+    parallel_ranges(n, NP, [&](int t, int32_t rb, int32_t re) {
         Part &P = parts[(size_t)t];
         std::vector<std::pair<int32_t, int32_t>> groups, tmp;
-        std::vector<Nam> local;
+        std::vector<Nam> local[2];
         std::vector<Inst> order;
+        ParseScratch scratch;
+        const int64_t span = re > rb ? (in->fw_end[re - 1] - in->fw_begin[rb]) + (in->rc_end[re - 1] - in->rc_begin[rb]) : 0;
+        if (span > 0) P.nams.reserve((size_t)(span / 16));       // a hit line is at least that long
+        P.insts.reserve((size_t)(re - rb) * 2); P.inst_per_read.reserve((size_t)(re - rb)); P.mod_len.reserve((size_t)(re - rb));
+        if (re > rb) (void)P.mod.room((size_t)(in->read_off[re] - in->read_off[rb]));
         for (int32_t r = rb; r < re && P.err.empty(); r++) {
             order.clear();
             for (int strand = 0; strand < 2; strand++) {
                 const int64_t b = strand ? in->rc_begin[r] : in->fw_begin[r], e = strand ? in->rc_end[r] : in->fw_end[r];
-                local.clear(); groups.clear();
-                if (e > b && !parse_hits(in->seed_text + b, in->seed_text + e, local, groups, P.err)) { P.err_read = r; break; }
+                std::vector<Nam> &loc = local[strand];
+                loc.clear(); groups.clear();
+                if (e > b && !parse_hits(in->seed_text + b, in->seed_text + e, loc, groups, scratch, P.err)) { P.err_read = r; break; }
                 for (auto &g : groups) {
-                    const Nam *gn = local.data() + g.first;
+                    const Nam *gn = loc.data() + g.first;
                     const int32_t chr = gn[0].chr;
                     if (chr >= in->n_chr || in->max_intron_chr[chr] < 0) { P.err = "chromosome id without an entry in max_intron_chr (KeyError in align.py:124)"; P.err_read = r; break; }
                     const int64_t limit = std::min<int64_t>(in->max_intron_chr[chr] + 20000, in->max_global_intron);
                     int32_t s = 0;
                     for (int32_t i = 1; i <= g.second; i++) {
-                        if (i == g.second || gn[i].x - gn[i - 1].y > limit) { // cut wherever two consecutive seeds are further apart (:133)
+                        if (i == g.second || (int64_t)gn[i].x - (int64_t)gn[i - 1].y > limit) { // cut wherever two consecutive seeds are further apart (:133)
                             Inst it;
-                            it.first = (int64_t)P.nams.size(); it.n = i - s; it.chr = chr; it.read = r; it.rc = (uint8_t)strand; it.limit = limit;
+                            it.first = g.first + s; it.n = i - s; it.chr = chr; it.read = r; it.rc = (uint8_t)strand; it.limit = limit;
                             it.bound = covered(gn + s, i - s, tmp);
-                            P.nams.insert(P.nams.end(), gn + s, gn + i);
                             order.push_back(it);
                             s = i;
                         }
@@ -225,65 +283,72 @@ int front_prepare(ultra_front *f, const ultra_front_input *in)
             }
             if (!P.err.empty()) break;
             // sorted(list(ub.items()) + list(ub_rc.items()), key=bound, reverse=True): stable (:442)
-            std::stable_sort(order.begin(), order.end(), [](const Inst &a, const Inst &b2) { return a.bound > b2.bound; });
-            // the NAMs of the read's instances follow the new order, so that instance i's NAMs are contiguous and ascending
+            if (order.size() > 1) stable_small_sort(order.data(), order.data() + order.size(), [](const Inst &a, const Inst &b2) { return a.bound > b2.bound; });
             P.inst_per_read.push_back((int32_t)order.size());
-            P.insts.insert(P.insts.end(), order.begin(), order.end());
+            for (Inst &it : order) {        // the NAMs follow that order: instance i's NAMs are contiguous and ascending in the part
+                const Nam *src = local[it.rc].data() + it.first;
+                it.first = (int64_t)P.nams.size();
+                P.nams.insert(P.nams.end(), src, src + it.n);
+                P.insts.push_back(it);
+            }
             // remove_read_polyA_ends(seq, qual, threshold, 1)[0]
             const uint8_t *seq = in->reads + in->read_off[r];
             const int64_t len = in->read_off[r + 1] - in->read_off[r];
             const int64_t window = std::min<int64_t>(len / 2, 100);
             const int64_t head = window == 0 ? 0 : len - window;      // seq[:-0] is '' and seq[-0:] the whole read
-            const size_t at = P.mod.size();
-            P.mod.insert(P.mod.end(), seq, seq + head);
+            uint8_t *dst = P.mod.room((size_t)len);                    // the trimmed read is never longer
+            memcpy(dst, seq, (size_t)head);
+            int64_t w = head;
             for (int64_t i = head; i < len;) {
-                int64_t j = i;
+                int64_t j = i + 1;
                 while (j < len && seq[j] == seq[i]) j++;
                 const int64_t run = j - i;
-                const int64_t keep = (run > in->polyA_threshold && (seq[i] == 'A' || seq[i] == 'T')) ? 1 : run;
-                P.mod.insert(P.mod.end(), (size_t)keep, seq[i]);
+                if (run > in->polyA_threshold && (seq[i] == 'A' || seq[i] == 'T')) dst[w++] = seq[i];
+                else { memcpy(dst + w, seq + i, (size_t)run); w += run; }
                 i = j;
             }
-            P.mod_len.push_back((int64_t)(P.mod.size() - at));
+            P.mod.n += (size_t)w;
+            P.mod_len.push_back(w);
         }
     });
     for (auto &P : parts)
         if (!P.err.empty()) return front_fail(f, ULTRA_E_ARG, "ultra_front: read " + std::to_string(P.err_read) + ": " + P.err);
-    // ---- concatenate in read order ----
-    f->nams.clear(); f->insts.clear(); f->mod.clear();
-    f->read_inst_off.assign(1, 0); f->mod_off.assign(1, 0);
-    size_t tn = 0, ti = 0, tm = 0;
-    for (auto &P : parts) { tn += P.nams.size(); ti += P.insts.size(); tm += P.mod.size(); }
-    f->nams.reserve(tn); f->insts.reserve(ti); f->mod.reserve(tm + 16);
-    for (auto &P : parts) {
-        const int64_t nam_base = (int64_t)f->nams.size();
-        f->nams.insert(f->nams.end(), P.nams.begin(), P.nams.end());
-        for (auto it : P.insts) { it.first += nam_base; f->insts.push_back(it); }
-        for (int32_t c : P.inst_per_read) f->read_inst_off.push_back(f->read_inst_off.back() + c);
-        f->mod.insert(f->mod.end(), P.mod.begin(), P.mod.end());
-        for (int64_t l : P.mod_len) f->mod_off.push_back(f->mod_off.back() + l);
+    // ---- every part to its place in read order (the chaining launch's arrays: instances in processing order, NAMs contiguous) ----
+    std::vector<size_t> nam_base((size_t)NP + 1, 0), inst_base((size_t)NP + 1, 0), mod_base((size_t)NP + 1, 0), read_base((size_t)NP + 1, 0);
+    for (int t = 0; t < NP; t++) {
+        nam_base[(size_t)t + 1] = nam_base[(size_t)t] + parts[(size_t)t].nams.size();
+        inst_base[(size_t)t + 1] = inst_base[(size_t)t] + parts[(size_t)t].insts.size();
+        mod_base[(size_t)t + 1] = mod_base[(size_t)t] + parts[(size_t)t].mod.n;
+        read_base[(size_t)t + 1] = read_base[(size_t)t] + parts[(size_t)t].inst_per_read.size();
     }
-    // ---- the chaining launch's arrays: instances in processing order, their NAMs contiguous ----
-    const size_t NI = f->insts.size();
-    f->inst_off.assign(NI + 1, 0);
-    f->intron.resize(std::max<size_t>(NI, 1));
-    f->ny.resize(std::max<size_t>(tn, 1)); f->nc.resize(std::max<size_t>(tn, 1)); f->nd.resize(std::max<size_t>(tn, 1));
-    {
-        // an instance's NAMs lie in the order they were produced (fw groups, then rc groups); the stable sort by bound
-        // moved the instance records, not the NAMs: gather them per instance
-        std::vector<Nam> ordered;
-        ordered.reserve(tn);
-        for (size_t i = 0; i < NI; i++) {
-            Inst &it = f->insts[i];
-            const int64_t nf = (int64_t)ordered.size();
-            ordered.insert(ordered.end(), f->nams.begin() + it.first, f->nams.begin() + it.first + it.n);
-            it.first = nf;
-            f->inst_off[i + 1] = f->inst_off[i] + it.n;
-            f->intron[i] = it.limit;
+    const size_t tn = nam_base[(size_t)NP], NI = inst_base[(size_t)NP];
+    f->n_nam = tn; f->n_inst = NI;
+    grow(f->nams, tn + 1); grow(f->insts, NI + 1); grow(f->mod, mod_base[(size_t)NP] + 16);
+    grow(f->read_inst_off, (size_t)n + 1); grow(f->mod_off, (size_t)n + 1);
+    grow(f->inst_off, NI + 1); grow(f->intron, NI + 1);
+    grow(f->ny, tn + 1); grow(f->nc, tn + 1); grow(f->nd, tn + 1);
+    f->read_inst_off[0] = 0; f->mod_off[0] = 0; f->inst_off[0] = 0;
+    parallel_ranges(NP, NP, [&](int, int32_t pb, int32_t pe) {
+        for (int32_t t = pb; t < pe; t++) {
+            const Part &P = parts[(size_t)t];
+            const size_t nb = nam_base[(size_t)t], ib = inst_base[(size_t)t], mb = mod_base[(size_t)t], rb = read_base[(size_t)t];
+            if (!P.nams.empty()) memcpy(f->nams.data() + nb, P.nams.data(), P.nams.size() * sizeof(Nam));
+            for (size_t k = 0; k < P.nams.size(); k++) { f->ny[nb + k] = P.nams[k].y; f->nc[nb + k] = P.nams[k].c; f->nd[nb + k] = P.nams[k].d; }
+            for (size_t i = 0; i < P.insts.size(); i++) {
+                Inst it = P.insts[i];
+                it.first += (int64_t)nb;
+                f->insts[ib + i] = it;
+                f->inst_off[ib + i + 1] = it.first + it.n;        // the next instance starts where this one ends
+                f->intron[ib + i] = it.limit;
+            }
+            if (P.mod.n) memcpy(f->mod.data() + mb, P.mod.p, P.mod.n);
+            int64_t ic = (int64_t)ib, mc = (int64_t)mb;
+            for (size_t r = 0; r < P.inst_per_read.size(); r++) {
+                ic += P.inst_per_read[r]; mc += P.mod_len[r];
+                f->read_inst_off[rb + r + 1] = ic; f->mod_off[rb + r + 1] = mc;
+            }
         }
-        f->nams.swap(ordered);
-        for (size_t k = 0; k < tn; k++) { f->ny[k] = (int32_t)f->nams[k].y; f->nc[k] = f->nams[k].c; f->nd[k] = f->nams[k].d; }
-    }
+    });
     return ULTRA_OK;
 }
 
@@ -291,12 +356,19 @@ int front_prepare(ultra_front *f, const ultra_front_input *in)
 int front_select(ultra_front *f, const ultra_front_input *in, int n_threads)
 {
     const int32_t n = in->n_reads;
-    struct SelPart { std::vector<Loc> locs; std::vector<int32_t> per_read; std::vector<int64_t> sol; std::vector<int64_t> limit; int64_t nq = 0, nl = 0; };
-    std::vector<SelPart> parts((size_t)std::max(1, std::min<int>(n_threads, std::max(n, 1))));
-    parallel_ranges(n, (int)parts.size(), [&](int t, int32_t rb, int32_t re) {
+    const int NP = std::max(1, std::min<int>(n_threads, std::max(n, 1)));
+    std::vector<SelPart> &parts = f->sel_parts;
+    if ((int)parts.size() < NP) parts.resize((size_t)NP);
+    for (auto &P : parts) P.reset();
+    parallel_ranges(n, NP, [&](int t, int32_t rb, int32_t re) {
         SelPart &P = parts[(size_t)t];
         struct Ch { int64_t inst; int32_t end; int64_t span, value; };
         std::vector<Ch> all;
+        std::vector<std::pair<size_t, int32_t>> pending;     // (first sol entry, count) of the part's locations: pointers once sol stops growing
+        if (re > rb) {
+            const int64_t nn = f->inst_off[(size_t)f->read_inst_off[re]] - f->inst_off[(size_t)f->read_inst_off[rb]];
+            P.sol.reserve((size_t)nn + 64); P.locs.reserve((size_t)(re - rb) * 2); P.per_read.reserve((size_t)(re - rb)); P.limit.reserve((size_t)(re - rb));
+        }
         for (int32_t r = rb; r < re; r++) {
             all.clear();
             int64_t best = 0, limit = -1;
@@ -313,59 +385,69 @@ int front_select(ultra_front *f, const ultra_front_input *in, int n_threads)
                     if (f->C[(size_t)(base + j)] != v) continue;
                     int32_t idx = j, first = j;
                     while (idx > 0) { first = idx; idx = f->trace[(size_t)(base + idx)]; }
-                    all.push_back({i, j, nm[j - 1].y - nm[first - 1].x, v});
+                    all.push_back({i, j, (int64_t)nm[j - 1].y - (int64_t)nm[first - 1].x, v});
                 }
             }
             P.limit.push_back(limit);
-            std::stable_sort(all.begin(), all.end(), [](const Ch &a, const Ch &b) { return a.value != b.value ? a.value > b.value : a.span < b.span; });
+            if (all.size() > 1) stable_small_sort(all.data(), all.data() + all.size(), [](const Ch &a, const Ch &b) { return a.value != b.value ? a.value > b.value : a.span < b.span; });
             int32_t kept = 0;
             for (size_t k = 0; k < all.size(); k++) {
                 if ((double)all[k].value / (double)all[0].value < in->dropoff || (int32_t)k >= in->max_loc) break;   // :472
                 const Inst &it = f->insts[(size_t)all[k].inst];
                 const int64_t base = f->inst_off[(size_t)all[k].inst] + all[k].inst;
                 Loc L;
-                L.read = r; L.chr = it.chr; L.rc = it.rc; L.score = all[k].value; L.sol_first = (int64_t)P.sol.size(); L.inst_first = it.first;
+                L.read = r; L.chr = it.chr; L.rc = it.rc; L.score = all[k].value; L.sol = nullptr; L.inst_first = it.first;
+                const size_t first = P.sol.size();
                 int32_t idx = all[k].end, cnt = 0;
                 while (idx > 0) { P.sol.push_back(it.first + idx - 1); idx = f->trace[(size_t)(base + idx)]; cnt++; }
-                std::reverse(P.sol.begin() + L.sol_first, P.sol.end());
+                std::reverse(P.sol.begin() + (int64_t)first, P.sol.end());
                 L.sol_n = cnt;
+                pending.push_back({first, cnt});
                 P.locs.push_back(L);
                 kept++;
             }
             P.per_read.push_back(kept);
         }
+        for (size_t l = 0; l < P.locs.size(); l++) P.locs[l].sol = P.sol.data() + pending[l].first;
     });
-    f->locs.clear(); f->loc_off.assign(1, 0); f->last_limit.clear();
+    // ---- one MAM-stage instance per location: offsets first (serial, two additions per location), then the parts in parallel ----
+    std::vector<size_t> loc_base((size_t)NP + 1, 0), read_base((size_t)NP + 1, 0);
     f->n_quadratic = f->n_nlogn = 0;
-    std::vector<int64_t> sol_all;
-    for (auto &P : parts) {
-        const int64_t sb = (int64_t)sol_all.size();
-        sol_all.insert(sol_all.end(), P.sol.begin(), P.sol.end());
-        for (auto L : P.locs) { L.sol_first += sb; f->locs.push_back(L); }
-        for (int32_t c : P.per_read) f->loc_off.push_back(f->loc_off.back() + c);
-        f->last_limit.insert(f->last_limit.end(), P.limit.begin(), P.limit.end());
-        f->n_quadratic += P.nq; f->n_nlogn += P.nl;
+    for (int t = 0; t < NP; t++) {
+        loc_base[(size_t)t + 1] = loc_base[(size_t)t] + parts[(size_t)t].locs.size();
+        read_base[(size_t)t + 1] = read_base[(size_t)t] + parts[(size_t)t].per_read.size();
+        f->n_quadratic += parts[(size_t)t].nq; f->n_nlogn += parts[(size_t)t].nl;
     }
-    // ---- the MAM stage's request: one instance per location ----
-    const size_t NL = f->locs.size();
-    f->loc_chr.resize(std::max<size_t>(NL, 1)); f->loc_rc.resize(std::max<size_t>(NL, 1)); f->loc_score.resize(std::max<size_t>(NL, 1));
-    f->rq_nam_off.assign(NL + 1, 0); f->rq_read_off.assign(NL + 1, 0);
-    for (size_t l = 0; l < NL; l++) {
-        const Loc &L = f->locs[l];
-        f->loc_chr[l] = L.chr; f->loc_rc[l] = L.rc; f->loc_score[l] = L.score;
-        f->rq_nam_off[l + 1] = f->rq_nam_off[l] + L.sol_n;
-        f->rq_read_off[l + 1] = f->rq_read_off[l] + (f->mod_off[(size_t)L.read + 1] - f->mod_off[(size_t)L.read]);
+    const size_t NL = loc_base[(size_t)NP];
+    f->n_loc = NL;
+    grow(f->locs, NL + 1); grow(f->loc_off, (size_t)n + 1); grow(f->last_limit, (size_t)n + 1);
+    grow(f->loc_chr, NL + 1); grow(f->loc_rc, NL + 1); grow(f->loc_score, NL + 1);
+    grow(f->rq_nam_off, NL + 1); grow(f->rq_read_off, NL + 1);
+    f->loc_off[0] = 0; f->rq_nam_off[0] = 0; f->rq_read_off[0] = 0;
+    {
+        size_t l = 0, r = 0;
+        for (int t = 0; t < NP; t++) {
+            const SelPart &P = parts[(size_t)t];
+            for (const Loc &L : P.locs) {
+                f->locs[l] = L;
+                f->rq_nam_off[l + 1] = f->rq_nam_off[l] + L.sol_n;
+                f->rq_read_off[l + 1] = f->rq_read_off[l] + (f->mod_off[(size_t)L.read + 1] - f->mod_off[(size_t)L.read]);
+                l++;
+            }
+            for (size_t k = 0; k < P.per_read.size(); k++, r++) { f->loc_off[r + 1] = f->loc_off[r] + P.per_read[k]; f->last_limit[r] = P.limit[k]; }
+        }
     }
     const size_t NS = (size_t)f->rq_nam_off[NL];
-    f->rq_part.resize(std::max<size_t>(3 * NS, 3)); f->rq_x.resize(std::max<size_t>(NS, 1)); f->rq_y.resize(std::max<size_t>(NS, 1));
-    f->sol_c.resize(std::max<size_t>(NS, 1)); f->sol_d.resize(std::max<size_t>(NS, 1)); f->sol_j.resize(std::max<size_t>(NS, 1));
-    f->rq_reads.resize((size_t)f->rq_read_off[NL] + 16);
+    grow(f->rq_part, 3 * NS + 3); grow(f->rq_x, NS + 1); grow(f->rq_y, NS + 1);
+    grow(f->sol_c, NS + 1); grow(f->sol_d, NS + 1); grow(f->sol_j, NS + 1);
+    grow(f->rq_reads, (size_t)f->rq_read_off[NL] + 16);
     std::atomic<int32_t> bad_read(-1);
     parallel_ranges((int32_t)NL, n_threads, [&](int, int32_t lb, int32_t le) {
         for (int32_t l = lb; l < le; l++) {
             const Loc &L = f->locs[(size_t)l];
+            f->loc_chr[(size_t)l] = L.chr; f->loc_rc[(size_t)l] = L.rc; f->loc_score[(size_t)l] = L.score;
             for (int32_t k = 0; k < L.sol_n; k++) {
-                const int64_t gi = sol_all[(size_t)(L.sol_first + k)];
+                const int64_t gi = L.sol[k];
                 const Nam &nm = f->nams[(size_t)gi];
                 const size_t o = (size_t)f->rq_nam_off[(size_t)l] + (size_t)k;
                 f->sol_j[o] = (int32_t)(gi - L.inst_first);
@@ -407,16 +489,16 @@ const char *ultra_front_last_error(const ultra_front *f) { return f ? f->err.c_s
 static void fill_view(ultra_front *f, ultra_front_view *v, bool with_locs, bool with_mam)
 {
     memset(v, 0, sizeof *v);
-    v->n_inst = (int64_t)f->insts.size();
+    v->n_inst = (int64_t)f->n_inst;
     v->read_inst_off = f->read_inst_off.data();
-    v->n_nam = (int64_t)f->nams.size();
+    v->n_nam = (int64_t)f->n_nam;
     v->inst_nam_off = f->inst_off.data();
     v->inst_intron = f->intron.data();
     v->nam_y = f->ny.data(); v->nam_c = f->nc.data(); v->nam_d = f->nd.data();
     v->read_mod = f->mod.data(); v->read_mod_off = f->mod_off.data();
     for (int i = 0; i < 6; i++) v->ms[i] = f->ms[i];
     if (!with_locs) return;
-    v->n_loc = (int64_t)f->locs.size();
+    v->n_loc = (int64_t)f->n_loc;
     v->loc_off = f->loc_off.data(); v->last_limit = f->last_limit.data();
     v->loc_chr = f->loc_chr.data(); v->loc_rc = f->loc_rc.data(); v->loc_score = f->loc_score.data();
     v->sol_off = f->rq_nam_off.data(); v->sol_part = f->rq_part.data(); v->sol_x = f->rq_x.data(); v->sol_y = f->rq_y.data();
@@ -443,8 +525,8 @@ int ultra_front_prepare(ultra_front *f, const ultra_front_input *in, ultra_front
     fill_view(f, view, false, false);
     view->inst_chr_rc_bound = nullptr;
     // per instance: chromosome, strand, bound, read - packed for the test as four int64 each
-    f->C.assign(4 * std::max<size_t>(f->insts.size(), 1), 0);
-    for (size_t i = 0; i < f->insts.size(); i++) {
+    grow(f->C, 4 * f->n_inst + 4);
+    for (size_t i = 0; i < f->n_inst; i++) {
         f->C[4 * i] = f->insts[i].chr; f->C[4 * i + 1] = f->insts[i].rc; f->C[4 * i + 2] = f->insts[i].bound; f->C[4 * i + 3] = f->insts[i].read;
     }
     view->inst_chr_rc_bound = f->C.data();
@@ -462,8 +544,8 @@ int ultra_front_run(ultra_front *f, ultra_ctx *ctx, const ultra_dindex *dix, con
     double t1 = now_ms();
     f->ms[0] = (float)(t1 - t0);
     // ---- ONE NAM chaining launch for every instance of the batch (align.py:448-453) ----
-    const size_t NI = f->insts.size(), NN = f->nams.size();
-    f->C.assign(NN + std::max<size_t>(NI, 1), 0); f->trace.assign(NN + std::max<size_t>(NI, 1), 0); f->value.assign(std::max<size_t>(NI, 1), 0);
+    const size_t NI = f->n_inst, NN = f->n_nam;
+    grow(f->C, NN + NI + 1); grow(f->trace, NN + NI + 1); grow(f->value, NI + 1);  // every entry in use is written by the launch
     if (NI > 0) {
         rc = ultra_chain_nams_batch(ctx, (int32_t)NI, f->inst_off.data(), f->ny.data(), f->nc.data(), f->nd.data(), f->intron.data(), 0,
                                     f->C.data(), f->trace.data(), f->value.data());
@@ -480,7 +562,7 @@ int ultra_front_run(ultra_front *f, ultra_ctx *ctx, const ultra_dindex *dix, con
     // ---- ONE device-planned MAM stage over every (read, location) (:487-489) ----
     ultra_plan_request rq;
     memset(&rq, 0, sizeof rq);
-    rq.n_inst = (int32_t)f->locs.size();
+    rq.n_inst = (int32_t)f->n_loc;
     rq.inst_nam_off = f->rq_nam_off.data(); rq.nam_part = f->rq_part.data(); rq.nam_x = f->rq_x.data(); rq.nam_y = f->rq_y.data();
     rq.reads = f->rq_reads.data(); rq.read_off = f->rq_read_off.data();
     rc = ultra_mam_stage_nams(ctx, dix, &rq);
@@ -500,10 +582,10 @@ int ultra_front_run(ultra_front *f, ultra_ctx *ctx, const ultra_dindex *dix, con
     int64_t nchain = 0, nmam = 0;
     rc = ultra_mam_sizes(ctx, &nchain, &nmam);
     if (rc != ULTRA_OK) return front_fail(f, rc, ultra_last_error(ctx));
-    const size_t ni = std::max<size_t>(f->locs.size(), 1), tc = (size_t)std::max<int64_t>(nchain, 1);
-    f->m_value.resize(ni); f->m_nmam.resize(ni); f->m_chain_off.resize(ni + 1);
-    f->m_cx.resize(tc); f->m_cy.resize(tc); f->m_cc.resize(tc); f->m_cd.resize(tc); f->m_cval.resize(tc); f->m_msl.resize(tc);
-    f->m_cand.resize(tc); f->m_cj.resize(tc); f->m_ckind.resize(tc); f->m_cchr.resize(tc);
+    const size_t ni = std::max<size_t>(f->n_loc, 1), tc = (size_t)std::max<int64_t>(nchain, 1);
+    grow(f->m_value, ni); grow(f->m_nmam, ni); grow(f->m_chain_off, ni + 1);
+    grow(f->m_cx, tc); grow(f->m_cy, tc); grow(f->m_cc, tc); grow(f->m_cd, tc); grow(f->m_cval, tc); grow(f->m_msl, tc);
+    grow(f->m_cand, tc); grow(f->m_cj, tc); grow(f->m_ckind, tc); grow(f->m_cchr, tc);
     fill_view(f, view, true, true);
     rc = ultra_mam_fetch(ctx, &view->mam);
     if (rc != ULTRA_OK) return front_fail(f, rc, std::string("ultra_front: fetch: ") + ultra_last_error(ctx));
