@@ -74,8 +74,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per leg (0 = skip)")
     ap.add_argument("--e2e-rounds", type=int, default=4, help="passes over the batches through ultra_pipe (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight in the end-to-end leg")
-    ap.add_argument("--overlap", type=int, default=2,
-                    help="host threads of the timed loop: 2 = the enumeration of the next batch rides beside the kernels of the current "
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="host threads of the timed loop (measured: no gain, the GPU is the bottleneck either way): 2 = the enumeration of the next batch rides beside the kernels of the current "
                          "one (two contexts, runs serialised), 1 = plan and run one after the other")
     ap.add_argument("--front-rounds", type=int, default=2, help="passes over two batches through the native front end (0 = skip)")
     ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
