@@ -487,11 +487,12 @@ def main():
             "value": reads_all / elapsed, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 bit-vectors / int32 scores (Myers), f64 (chaining)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] synthetic form (SURVEY.md 8d C3): %d-gene / %d-chromosome GENCODE-shaped annotation with "
+            "config": {"workload": {"ont_cdna": "BASELINE configs[2] synthetic form (SURVEY.md 8d C3)", "isoseq": "BASELINE configs[1] synthetic form (SURVEY.md 8d C2)",
+                                    "ont_drna": "BASELINE configs[4] synthetic form (SURVEY.md 8d C5)"}[args.preset] + " on world '%s': %d-gene / %d-chromosome GENCODE-shaped annotation with "
                                    "overlapping genes (%d transcripts, %d segments), %d distinct %s reads per GPU (err %.2f, lengths drawn from the "
                                    "preset's model and cut to the transcript: mean %d bp) as %d batches of %d, reads + NAM chains + index "
                                    "resident in HBM, one step = enumeration + alignment + chaining of one batch"
-                                   % (wkw["n_genes"], wkw["n_chr"], len(w.transcripts), len(w.ref_segment_sequences), args.reads * nb, args.preset,
+                                   % (args.world, wkw["n_genes"], wkw["n_chr"], len(w.transcripts), len(w.ref_segment_sequences), args.reads * nb, args.preset,
                                       P["err"], int(np.mean([rs.reads.size / max(len(rs), 1) for rs in sets])), nb, args.reads),
                        "reads_per_gpu_per_step": args.reads, "distinct_batches_per_gpu": nb, "pairs_per_step_per_gpu": n_pairs,
                        "candidates_per_step_per_gpu": n_cands, "cells_per_step_per_gpu": cells_step, "cells_per_read": cells_step / args.reads,
