@@ -36,7 +36,13 @@ enum { kBandClasses = 8, kBandFallback = 8 }; // banded traceback: 32 rows, then
 __host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : 16; } // classes 1..7
 __host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 2 : c == 4 ? 3 : c == 5 ? 4 : c == 6 ? 4 : 8; }    // lanes per hit
 __host__ __device__ constexpr int band_rows(int c) { return c == 0 ? 32 : 64 * band_words(c); }
-__host__ __device__ constexpr int band_chunk(int c) { return c == 0 ? 32 : c == 1 ? 16 : 8; } // columns per checkpoint
+#ifndef ULTRA_BAND_K0
+#define ULTRA_BAND_K0 32
+#endif
+#ifndef ULTRA_BAND_K1
+#define ULTRA_BAND_K1 16
+#endif
+__host__ __device__ constexpr int band_chunk(int c) { return c == 0 ? ULTRA_BAND_K0 : c == 1 ? ULTRA_BAND_K1 : 8; } // columns per checkpoint
 
 struct MyArgs {
     const uint8_t *seq, *rseq;
@@ -791,7 +797,7 @@ __global__ void __launch_bounds__(64) myers_mega(MyArgs a, const WorkItem *list,
 // recomputing one chunk's K columns from its checkpoint into LDS ({Pv, Ph} per column) and walking
 // inside LDS.  Twice the (cheap, banded) arithmetic instead of 16*WB bytes per column and lane of
 // HBM traffic plus a dependent load per walk step.
-template <int WB> struct BandK { static constexpr int K = WB <= 1 ? 16 : 8; }; // columns per chunk
+template <int WB> struct BandK { static constexpr int K = WB <= 1 ? band_chunk(1) : 8; }; // columns per chunk
 
 template <int WB, int NP>
 __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items, int64_t n_items)
@@ -1893,6 +1899,25 @@ constexpr int kBuckets = 5;
 inline int bucket_of(int cls) { return cls < 2 ? 0 : cls < 4 ? 1 : cls < 6 ? 2 : cls < 10 ? 3 : 4; } // the long class rides in bucket 4
 inline int bucket_wmax(int b) { return b == 0 ? 2 : b < 4 ? 4 : 8; } // words per lane: LDS per wavefront = S * wmax * 512 B
 
+// Development knob: a comma-separated list of small integers from the environment (lane assignments of a pass), read
+// once; absent or malformed = the built-in assignment.
+struct DevList { int n = 0; int v[16] = {}; };
+DevList dev_list(const char *name)
+{
+    DevList d;
+    const char *e = getenv(name);
+    if (!e || !*e) return d;
+    while (*e && d.n < 16) {
+        char *end = nullptr;
+        const long x = strtol(e, &end, 10);
+        if (end == e || x < 0 || x > 64) { d.n = 0; return d; }
+        d.v[d.n++] = (int)x;
+        e = *end == ',' ? end + 1 : end;
+        if (*end && *end != ',') { d.n = 0; return d; }
+    }
+    return d;
+}
+
 // part / parts: this launch takes every parts-th work item of the list starting with item `part`, on lane `lane_i`
 template <int MODE> hipError_t launch_mega(ultra_ctx *ctx, MyArgs a, int bucket, const WorkItem *d_list, int32_t n, int part = 0, int parts = 1, int lane_i = -1)
 {
@@ -2069,13 +2094,30 @@ __global__ void __launch_bounds__(256) k_presence(const uint8_t *raw, int64_t n,
     __shared__ uint32_t sm[8];
     if (threadIdx.x < 8) sm[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t b = raw[i];
-        loc[b >> 5] |= 1u << (b & 31);
-    }
+    // 16 bytes per load; the letters (64 .. 127: all a sequence file normally holds) collect in one 64-bit register,
+    // anything else goes to LDS directly (rare)
+    uint64_t mid = 0;
+    auto one = [&](uint32_t b) {
+        if ((b >> 6) == 1u) mid |= (uint64_t)1 << (b & 63);
+        else atomicOr(&sm[b >> 5], 1u << (b & 31));
+    };
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    int64_t head = (int64_t)((16 - ((uintptr_t)raw & 15)) & 15);
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) / 16;
+    const uint4 *v = (const uint4 *)(raw + head);
+    for (int64_t i = tid; i < nvec; i += nt) {
+        const uint4 x = v[i];
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-    for (int w = 0; w < 8; w++) if (loc[w]) atomicOr(&sm[w], loc[w]);
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int sft = 0; sft < 32; sft += 8) one((w[j] >> sft) & 0xffu);
+    }
+    for (int64_t i = tid; i < head; i += nt) one(raw[i]);
+    for (int64_t i = head + nvec * 16 + tid; i < n; i += nt) one(raw[i]);
+    if ((uint32_t)mid) atomicOr(&sm[2], (uint32_t)mid);
+    if ((uint32_t)(mid >> 32)) atomicOr(&sm[3], (uint32_t)(mid >> 32));
     __syncthreads();
     if (threadIdx.x < 8 && sm[threadIdx.x]) atomicOr(&mask[threadIdx.x], sm[threadIdx.x]);
 }
@@ -2086,7 +2128,20 @@ __global__ void __launch_bounds__(256) k_encode(const uint8_t *raw, int64_t n, c
     __shared__ uint8_t sl[256];
     sl[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // eight bytes per thread and step: one load, eight table look-ups, one store each way (the mirror image byte-swapped)
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n8 = n / 8;
+    for (int64_t i = tid; i < n8; i += nt) {
+        uint64_t x;
+        __builtin_memcpy(&x, raw + 8 * i, 8);
+        uint64_t y = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) y |= (uint64_t)sl[(x >> (8 * j)) & 0xff] << (8 * j);
+        __builtin_memcpy(seq + at + 8 * i, &y, 8);
+        const uint64_t z = __builtin_bswap64(y);
+        __builtin_memcpy(rseq + (N - (at + 8 * i) - 8), &z, 8);
+    }
+    for (int64_t i = 8 * n8 + tid; i < n; i += nt) {
         const uint8_t c = sl[raw[i]];
         seq[at + i] = c;
         rseq[N - 1 - (at + i)] = c;
@@ -2109,9 +2164,13 @@ constexpr int kStatN = 16;
 __global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const int32_t *t_len, const int32_t *k, int32_t n, uint32_t *keys,
                                                    int32_t *idx, unsigned long long *stats)
 {
-    __shared__ unsigned long long sh[4 * kStatN];
-    for (int i = threadIdx.x; i < 4 * kStatN; i += blockDim.x) sh[i] = 0;
+    // 16 copies of the counters, a thread uses copy (thread & 15): the pairs of a wavefront mostly fall into two or three
+    // classes, and 64 lanes adding to one LDS address take 64 turns
+    constexpr int kCopies = 16;
+    __shared__ unsigned long long shc[kCopies][4 * kStatN];
+    for (int i = threadIdx.x; i < kCopies * 4 * kStatN; i += blockDim.x) (&shc[0][0])[i] = 0;
     __syncthreads();
+    unsigned long long *sh = shc[threadIdx.x & (kCopies - 1)];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) {
         const int m = q_len[p], t = t_len[p];
@@ -2128,8 +2187,10 @@ __global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const i
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * kStatN; i += blockDim.x) {
-        if (!sh[i]) continue;
-        if (i < 2 * kStatN) atomicAdd(&stats[i], sh[i]); else atomicMax(&stats[i], sh[i]);
+        unsigned long long v = 0;
+        for (int c2 = 0; c2 < kCopies; c2++) v = i < 2 * kStatN ? v + shc[c2][i] : (shc[c2][i] > v ? shc[c2][i] : v);
+        if (!v) continue;
+        if (i < 2 * kStatN) atomicAdd(&stats[i], v); else atomicMax(&stats[i], v);
     }
 }
 
@@ -2447,18 +2508,32 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     for (int b = kBuckets - 1; b >= 0; b--) {
         MyersBucket &bk = st.buckets[b];
         if (bk.n_fwd <= 0) continue;
-        hipStream_t cs = ctx->lane(b);
+        const int lane_b = b == kBuckets - 1 && ctx->cfg.launch_lanes >= kBuckets + 3 ? kBuckets + 2 : b;
+        hipStream_t cs = ctx->lane(lane_b);
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev0, cs));
         // The workgroup dispatcher deals the chip's slots about evenly over the launches in flight, not by their work:
         // the bucket of the three- and four-word lane classes (m = 129 .. 256 against long targets) finished 1.5 - 2 ms
         // after the others.  With lanes to spare its list is dealt over three launches (interleaved, so each keeps the
         // heaviest-first order) and takes three shares: the buckets then end within a millisecond of each other
         // (measured: forward phase 13.0 -> 12.4 ms; a second launch for the lane groups' bucket as well: 12.6).
+        static const DevList dev_fwd = dev_list("ULTRA_DEV_FWD_LANES"); // parts of bucket 1, then lanes: b0, b1 part 0 / 1 / 2, b2, b3, b4
+        if (dev_fwd.n == 8) {
+            const int parts = dev_fwd.v[0] < 1 ? 1 : dev_fwd.v[0] > 3 ? 3 : dev_fwd.v[0];
+            const int lane_of[5] = {dev_fwd.v[1], dev_fwd.v[2], dev_fwd.v[5], dev_fwd.v[6], dev_fwd.v[7]};
+            if (b == 1 && bk.n_fwd >= 64) {
+                for (int pi = 0; pi < parts; pi++)
+                    ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, pi, parts, dev_fwd.v[2 + pi]));
+            } else ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 0, 1, lane_of[b]));
+            ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev1, cs));
+            continue;
+        }
         if (ctx->cfg.launch_lanes >= kBuckets + 3 && b == 1 && bk.n_fwd >= 64) {
+            // parts on lanes 1, 4, 5 and the widest bucket (few, long wavefronts) on the last lane: the third part on lane 6
+            // started only when the second had ended (12.4 -> 12.1 ms; scripts/dev/lane_variants.sh)
             ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 0, 3));
-            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 1, 3, kBuckets));
-            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 2, 3, kBuckets + 1));
-        } else ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd));
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 1, 3, kBuckets - 1));
+            ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 2, 3, kBuckets));
+        } else ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 0, 1, lane_b));
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev1, cs));
     }
     ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
@@ -2739,7 +2814,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             at += (size_t)region[c] * (size_t)units[c];
             const int32_t *items = items_sorted + band_first[c];
             const dim3 grid((unsigned)units[c]), block(64);
-            hipStream_t cs = ctx->lane(c);
+            static const DevList dev_tb = dev_list("ULTRA_DEV_TB_LANES"); // lane of band class 0 .. 7
+            // With eight lanes the classes go to lanes 4 .. 7, 0 .. 3: measured 0.45 ms shorter than class c on lane c, where
+            // the 4-word class regularly started only when the 1-word class had ended (lanes i and i + 4 seem to share a
+            // dispatch pipe; scripts/ubench/dispatch.hip, scripts/dev/lane_variants.sh)
+            hipStream_t cs = ctx->lane(dev_tb.n == kBandClasses ? dev_tb.v[c] : ctx->cfg.launch_lanes == 8 ? (c + 4) % 8 : c);
             const int64_t ni = h_band[c];
             const int WB = band_words(c);
             const size_t band_lds = (size_t)band_chunk(c) * band_rows(c) * 16; // K columns x {Pv, Ph} of the window per lane
