@@ -2171,8 +2171,8 @@ __global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const i
     for (int i = threadIdx.x; i < kCopies * 4 * kStatN; i += blockDim.x) (&shc[0][0])[i] = 0;
     __syncthreads();
     unsigned long long *sh = shc[threadIdx.x & (kCopies - 1)];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) {
+    // a few thousand blocks, each over many pairs: every block ends with up to 64 atomics on the same global counters
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const int m = q_len[p], t = t_len[p];
         const uint32_t c = pair_cannot_hit(m, t, k[p]) ? kSkipClass : size_class_of(m);
         // Lane classes (m <= 256): queries that leave the lower half of their first word empty sort together, so that
@@ -2285,7 +2285,7 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
     int32_t *i_in = (int32_t *)(k_out + np), *i_out = i_in + np;
     const unsigned gp = (unsigned)((n_pairs + 255) / 256);
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.stats.p, 0, 4 * kStatN * 8, s));
-    hipLaunchKernelGGL(k_pair_keys, dim3(gp), dim3(256), 0, s, st.u_qlen.as<int32_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(), n_pairs,
+    hipLaunchKernelGGL(k_pair_keys, dim3(std::min(gp, 2048u)), dim3(256), 0, s, st.u_qlen.as<int32_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(), n_pairs,
                        k_in, i_in, st.stats.as<unsigned long long>());
     {
         size_t tmp_bytes = 0;
@@ -2505,7 +2505,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[0], s));
     // ---- pass 1: forward HW ----
     ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
-    for (int b = kBuckets - 1; b >= 0; b--) {
+    static const DevList dev_order = dev_list("ULTRA_DEV_FWD_ORDER"); // buckets in launch order
+    for (int bi = 0; bi < kBuckets; bi++) {
+        const int b = dev_order.n == kBuckets && dev_order.v[bi] < kBuckets ? dev_order.v[bi] : kBuckets - 1 - bi;
         MyersBucket &bk = st.buckets[b];
         if (bk.n_fwd <= 0) continue;
         const int lane_b = b == kBuckets - 1 && ctx->cfg.launch_lanes >= kBuckets + 3 ? kBuckets + 2 : b;
