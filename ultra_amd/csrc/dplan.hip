@@ -70,6 +70,9 @@ struct PlanArgs {
     int32_t *q_len, *t_len, *k;
     int32_t *read_len;
     int64_t *fps, *lps;
+    // what the count pass found out about an instance, kept for the fill pass (which then starts at the candidate list
+    // instead of repeating the look-ups and sorts): state_stride ints per instance / list entry, plan_state_ints<CAP>()
+    int32_t *state; int64_t state_stride;
 };
 
 __device__ __forceinline__ void plan_error(const PlanArgs &a, int code, int inst)
@@ -151,7 +154,27 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
     int64_t fps = (int64_t)1 << 32, lps = 0;
     int nh = 0, nf = 0;
     bool too_big = false;
-
+    int U = 0, C0 = 0, nfp = 0, npair = 0;
+    int32_t *const stp = a.state + (int64_t)(a.list ? (int)blockIdx.x : inst) * a.state_stride;
+    constexpr int kStateHdr = 16;
+    if constexpr (FILL) {
+        // ---- the count pass's findings: header, then the lists back to back ----
+        // an overflow instance of the small-capacity launch: the launch with the larger capacity takes it (its count pass has
+        // overwritten n_cand by now, so the mark is in the state's header)
+        if (a.n_cand[inst] < 0 || stp[0] < 0) return;
+        C0 = stp[0]; U = stp[1]; nf = stp[2]; nfp = stp[3]; npair = stp[4];
+        fps = (int64_t)(((uint64_t)(uint32_t)stp[6] << 32) | (uint32_t)stp[5]);
+        lps = (int64_t)(((uint64_t)(uint32_t)stp[8] << 32) | (uint32_t)stp[7]);
+        const int32_t *q = stp + kStateHdr;
+        for (int i = lane; i < C0; i += 64) A2[i] = q[i];
+        q += C0;
+        for (int i = lane; i < U; i += 64) { uh_seg[i] = q[i]; uh_x[i] = q[U + i]; uh_y[i] = q[2 * U + i]; uh_full[i] = q[3 * U + i]; }
+        q += 4 * U;
+        for (int i = lane; i < C0 + nf; i += 64) pre[i] = q[i];
+        q += C0 + nf;
+        for (int i = lane; i < nf; i += 64) { fl_id[i] = q[i]; fl_x[i] = q[nf + i]; fl_y[i] = q[2 * nf + i]; fl_pos[i] = q[3 * nf + i]; fl_part[i] = q[4 * nf + i]; }
+        __syncthreads();
+    } else {
     // ---- get_unique_exon_and_flank_locations (:180-253) ----
     for (int64_t base = n0; base < n1; base += 64) {
         const int64_t u = base + lane;
@@ -237,7 +260,6 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
     __syncthreads();
 
     // ---- unique hit segments: first NAM's start, last NAM's end ----
-    int U = 0;
     if (!too_big && nh > 0) {
         wave_sort(keysA, nh, lane);
         for (int base = 0; base < nh; base += 64) {
@@ -301,7 +323,6 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
     }
 
     // ---- get_unique_segment_and_flank_choordinates (:256-300): small segments of every hit gene, then the hit segments ----
-    int C0 = 0;
     if (!too_big && U > 0) {
         // genes of the hit segments -> sorted, unique
         int ng_raw = 0;
@@ -394,15 +415,12 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
     }
     __syncthreads();
     if (too_big) {
-        if (FILL) return; // cannot happen: the count pass sorted this instance out
         if (CAP >= 2048) { plan_error(a, PERR_TOO_BIG, inst); if (lane == 0) { a.n_cand[inst] = 0; a.n_pair[inst] = 0; } }
-        else if (lane == 0) { const int w = atomicAdd(a.overflow_cnt, 1); a.overflow_list[w] = inst; a.n_cand[inst] = -1; a.n_pair[inst] = 0; }
+        else if (lane == 0) { const int w = atomicAdd(a.overflow_cnt, 1); a.overflow_list[w] = inst; a.n_cand[inst] = -1; a.n_pair[inst] = 0; stp[0] = -1; }
         return;
     }
-    if (FILL && a.n_cand[inst] < 0) return;
 
     // ---- flanks: candidate order by start (stable in first-seen order), 5 % rule for the partial pieces (:288-295) ----
-    int nfp = 0;
     if (lane == 0) {
         for (int t = 0; t < nf; t++) {
             const FlankRec r = a.flank[fl_id[t]];
@@ -418,6 +436,7 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
     }
     __syncthreads();
     nfp = genes[0];
+    } // !FILL
     const int B1 = C0, B2 = C0 + nf, B3 = B2 + 2 * U, C = B3 + 2 * nfp;
 
     auto view = [&](int ci) {
@@ -469,8 +488,8 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
         dup = v.kind >= 2 && v.whole; // the same (query, target, k) as the full candidate's call: shared, as the host planner does
     };
 
+    if constexpr (!FILL) {
     // ---- pass over the candidates: pair numbering (prefix sums in candidate order) ----
-    int npair = 0;
     for (int base = 0; base < C; base += 64) {
         const int ci = base + lane;
         int add = 0;
@@ -488,10 +507,22 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
         npair += __shfl(incl, 63, 64);
     }
     __syncthreads();
-    if (!FILL) {
-        if (lane == 0) { a.n_cand[inst] = C; a.n_pair[inst] = npair; if (C > *(volatile int32_t *)a.max_cand) atomicMax(a.max_cand, C); } // one address: an unconditional atomic per wavefront serialised the launch (3 ms)
-        return;
+    if (lane == 0) {
+        a.n_cand[inst] = C; a.n_pair[inst] = npair; if (C > *(volatile int32_t *)a.max_cand) atomicMax(a.max_cand, C); // one address: an unconditional atomic per wavefront serialised the launch (3 ms)
+        stp[0] = C0; stp[1] = U; stp[2] = nf; stp[3] = nfp; stp[4] = npair;
+        stp[5] = (int32_t)(uint32_t)(uint64_t)fps; stp[6] = (int32_t)(uint32_t)((uint64_t)fps >> 32);
+        stp[7] = (int32_t)(uint32_t)(uint64_t)lps; stp[8] = (int32_t)(uint32_t)((uint64_t)lps >> 32);
     }
+    int32_t *q = stp + kStateHdr;
+    for (int i = lane; i < C0; i += 64) q[i] = A2[i];
+    q += C0;
+    for (int i = lane; i < U; i += 64) { q[i] = uh_seg[i]; q[U + i] = uh_x[i]; q[2 * U + i] = uh_y[i]; q[3 * U + i] = uh_full[i]; }
+    q += 4 * U;
+    for (int i = lane; i < B2; i += 64) q[i] = pre[i];
+    q += B2;
+    for (int i = lane; i < nf; i += 64) { q[i] = fl_id[i]; q[nf + i] = fl_x[i]; q[2 * nf + i] = fl_y[i]; q[3 * nf + i] = fl_pos[i]; q[4 * nf + i] = fl_part[i]; }
+    return;
+    } // !FILL
 
     // ---- fill ----
     const int64_t cbase = a.cand_off[inst], pbase = a.pair_off[inst];
@@ -571,6 +602,7 @@ __global__ void k_close_scan(const uint64_t *in, uint64_t *out, int64_t n)
     if (threadIdx.x == 0 && blockIdx.x == 0) out[n] = n > 0 ? out[n - 1] + in[n - 1] : 0;
 }
 
+template <int CAP> constexpr int64_t plan_state_ints() { return 16 + 6 * (int64_t)CAP + 6 * kMaxFlanks; } // header, full candidates, 4 x hit segments, pair prefixes, 5 x flanks
 template <int CAP> constexpr size_t plan_lds_bytes() { return (size_t)CAP * 16 + (size_t)CAP * 4 * 6 + (size_t)(2 * (kMaxGenes + 1) + 5 * kMaxFlanks) * 4 + 64; }
 
 } // namespace
@@ -837,6 +869,8 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     a.overflow_list = m.p_over.as<int32_t>();
     int32_t *misc = m.p_misc.as<int32_t>(); // [0] overflow count, [1..2] error code / instance, [3] largest candidate count
     a.overflow_cnt = misc; a.err = misc + 1; a.max_cand = misc + 3;
+    ULTRA_HIP_CHECK(ctx, m.p_state.ensure(NI * (size_t)plan_state_ints<128>() * 4));
+    a.state = m.p_state.as<int32_t>(); a.state_stride = plan_state_ints<128>();
     constexpr int CAP_S = 128, CAP_L = 2048; // 128 entries hold 99 % of the instances and let a CU keep twice the wavefronts in flight (the kernel is a chain of dependent loads)
     hipLaunchKernelGGL((k_plan<CAP_S, false>), dim3((unsigned)ni), dim3(64), plan_lds_bytes<CAP_S>(), s, a);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
@@ -858,8 +892,10 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     if (n_over > 0) {
         ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute(big_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds_bytes<CAP_L>()));
         ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute(big_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds_bytes<CAP_L>()));
+        ULTRA_HIP_CHECK(ctx, m.p_state_big.ensure((size_t)n_over * (size_t)plan_state_ints<CAP_L>() * 4));
         PlanArgs b = a;
         b.list = a.overflow_list; b.n_list = n_over;
+        b.state = m.p_state_big.as<int32_t>(); b.state_stride = plan_state_ints<CAP_L>();
         hipLaunchKernelGGL((k_plan<CAP_L, false>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_L>(), s, b);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -909,6 +945,7 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     if (n_over > 0) {
         PlanArgs b = a;
         b.list = a.overflow_list; b.n_list = n_over;
+        b.state = m.p_state_big.as<int32_t>(); b.state_stride = plan_state_ints<CAP_L>();
         hipLaunchKernelGGL((k_plan<CAP_L, true>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_L>(), s, b);
     }
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
