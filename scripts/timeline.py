@@ -13,7 +13,7 @@ i0 = starts[-1]
 t0 = int(tr[i0]['Start_Timestamp'])
 for r in tr[i0:]:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-    if d < 0.05:
+    if d < (float(sys.argv[2]) if len(sys.argv) > 2 else 0.05):
         continue
     n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:44]
     print("%8.3f +%7.3f ms  %s" % ((int(r['Start_Timestamp']) - t0) / 1e6, d, n))

@@ -85,7 +85,8 @@ struct MyersState {
     int64_t reads_cap = 0;
     uint8_t h_lut[256] = {};
     bool h_seen[256] = {};
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [5] traceback counts on the host, [6] the caller's mid-run work done
+    int32_t *h_route = nullptr;  // page-locked landing place of the traceback routing's counts
     bool times_pending = false;  // the last run returned before its final synchronisation (ultra_myers_run_impl, defer_sync)
 };
 

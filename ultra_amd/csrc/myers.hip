@@ -34,7 +34,16 @@ enum { kBandClasses = 8, kBandFallback = 8 }; // banded traceback: 32 rows, then
 // which is also what lets the band reach 16 words (distance <= 1014) before the full-height kernels take over (a
 // 24-word class over 8 lanes measured slower than those for the few hits beyond).
 __host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : 16; } // classes 1..7
+#ifndef ULTRA_BANDG_GEOM
+#define ULTRA_BANDG_GEOM 1
+#endif
+#if ULTRA_BANDG_GEOM == 0
 __host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 2 : c == 4 ? 3 : c == 5 ? 4 : c == 6 ? 4 : 8; }    // lanes per hit
+#else
+// one word per lane up to 8 words, two beyond: the wide bands are few, long wavefronts whose length is the length of the
+// traceback phase, and a column costs a lane about 30 instructions + 40 per word
+__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 6 : 8; }    // lanes per hit
+#endif
 __host__ __device__ constexpr int band_rows(int c) { return c == 0 ? 32 : 64 * band_words(c); }
 #ifndef ULTRA_BAND_K0
 #define ULTRA_BAND_K0 32
@@ -1055,7 +1064,7 @@ __global__ void __launch_bounds__(64) myers_bandg(MyArgs a, const int32_t *items
         // value of lane + 1 as a DPP move (a VALU instruction, not a trip through the LDS crossbar): groups of 2, 4 and 8
         // lanes never straddle a row of 16, groups of 3 do
         auto from_next_lane = [&](int v) {
-            return G == 3 ? __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
+            return (G == 3 || G == 6) ? __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
                           : __builtin_amdgcn_update_dpp(0, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
         };
         auto push_row = [&](uint32_t code1) { // the whole window moves down one row; the top lane takes the new row's code
@@ -1644,34 +1653,49 @@ __device__ __forceinline__ uint32_t tb_length_bin(uint32_t L) // 0 .. 767
     const uint32_t b = 256u + (uint32_t)(e - 8) * 32u + ((L >> (e - 5)) & 31u);
     return b < 767u ? b : 767u;
 }
-// info[kBandBounds + c] = longest first location of band class c; info[kBandBounds + kBandClasses + size class] =
-// largest distance among the hits no band class takes (sizes the stored band of the lane-group kernels)
+// COUNT: what the host needs to lay the launches out - hits per group (info[g]: the band classes, then the size classes
+// of the hits no band class takes) and info[kBandBounds + g] = the longest first location of a band class / the largest
+// distance of a size class.  It only needs the forward pass (the class follows from the distance), so it runs in front
+// of the start pass; the first location's start is not known then, and its length is bounded by m + ed (an alignment
+// of m query bases with ed edits) and by the target.  !COUNT: the sort keys, with the exact length, after the start pass.
+template <bool COUNT>
 __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uint32_t *keys, int32_t *info)
 {
-    // the maxima go through LDS: the hits come in the order of the sorted pairs, lengths growing, and a maximum kept
-    // with one global atomic per hit would take one almost every time
-    __shared__ int32_t top[kBandClasses + kNumSizeClasses];
-    if (threadIdx.x < kBandClasses + kNumSizeClasses) top[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the maxima and counts go through LDS: the hits come in the order of the sorted pairs, lengths growing, and a
+    // maximum kept with one global atomic per hit would take one almost every time
+    __shared__ int32_t top[kBandClasses + kNumSizeClasses], cnt[kBandClasses + kNumSizeClasses];
+    if (COUNT) {
+        if (threadIdx.x < kBandClasses + kNumSizeClasses) { top[threadIdx.x] = 0; cnt[threadIdx.x] = 0; }
+        __syncthreads();
+    }
+    // COUNT: a few hundred blocks, each over many hits (every block ends with atomics on the same few global counters)
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n_hits; i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + threadIdx.x;
     int slot = -1, v = 0;
     if (i < n_hits) {
         const int32_t p = a.hit_pairs[i];
         const int ed = a.ed[p];
-        const int64_t lo = a.loc_off[p];
-        const uint32_t L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
+        uint32_t L;
+        if (COUNT) {
+            const int32_t mq = a.q_len[p], tl = a.t_len[p];
+            L = (uint32_t)(mq + ed < tl ? mq + ed : tl);
+        } else {
+            const int64_t lo = a.loc_off[p];
+            L = (uint32_t)(a.loc_end[lo] - a.loc_start[lo] + 1);
+        }
         // ed + 1 diagonals, one spare on either side, up to 7 lost to the window's 8-row alignment: ed <= 64 WB - 10
         uint32_t c = 0;
         while (c < kBandFallback && ed > band_rows((int)c) - 10) c++;
         if (c < kBandFallback) {
-            keys[i] = c * kTbBins + (kTbBins - 1 - tb_length_bin(L));
+            if (!COUNT) keys[i] = c * kTbBins + (kTbBins - 1 - tb_length_bin(L));
             slot = (int)c; v = (int)L;
         } else {
             const uint32_t sc = size_class_of(a.q_len[p]);
-            keys[i] = kBandClasses * kTbBins + sc * kTbFullBins + (kTbFullBins - 1 - (tb_length_bin(L) >> 5));
+            if (!COUNT) keys[i] = kBandClasses * kTbBins + sc * kTbFullBins + (kTbFullBins - 1 - (tb_length_bin(L) >> 5));
             slot = kBandClasses + (int)sc; v = ed;
         }
     }
+    if (!COUNT) continue;
     {
         // nearly every lane of a wavefront has the slot of its first lane: one LDS atomic for them all (every lane takes
         // part in the exchange, the ones past the end with no slot), the others on their own
@@ -1679,29 +1703,19 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
         int vm = slot == slot0 ? v : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(vm, o, 64); vm = t > vm ? t : vm; }
-        if ((threadIdx.x & 63) == 0 && slot0 >= 0 && vm > top[slot0]) atomicMax(&top[slot0], vm);
-        if (slot >= 0 && slot != slot0 && v > top[slot]) atomicMax(&top[slot], v);
+        const int same = __popcll(__ballot(slot == slot0 && slot >= 0));
+        if ((threadIdx.x & 63) == 0 && slot0 >= 0) { if (vm > top[slot0]) atomicMax(&top[slot0], vm); atomicAdd(&cnt[slot0], same); }
+        if (slot >= 0 && slot != slot0) { if (v > top[slot]) atomicMax(&top[slot], v); atomicAdd(&cnt[slot], 1); }
     }
+    }
+    if (!COUNT) return;
     __syncthreads();
     if (threadIdx.x < kBandClasses + kNumSizeClasses) {
         const int32_t v = top[threadIdx.x];
         int32_t *g = info + kBandBounds + threadIdx.x;
         if (v > *(volatile int32_t *)g) atomicMax(g, v);
+        if (cnt[threadIdx.x]) atomicAdd(info + threadIdx.x, cnt[threadIdx.x]);
     }
-}
-// info[g] = first sorted position of group g (the band classes, then the size classes of the rest, then the end)
-__global__ void k_band_groups(const uint32_t *keys, int64_t n, int32_t *info)
-{
-    const int g = threadIdx.x;
-    if (g >= kBandBounds) return;
-    const uint32_t thr = g < kBandClasses ? (uint32_t)g * kTbBins : kBandClasses * kTbBins + (uint32_t)(g - kBandClasses) * kTbFullBins;
-    int64_t lo = 0, hi = n;
-    if (g == kBandBounds - 1) lo = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < thr) lo = mid + 1; else hi = mid;
-    }
-    info[g] = (int32_t)lo;
 }
 // keys of the banded start pass (k_start_keys below):
 // info[g] = first sorted position of group g (the band classes, then the 14 size classes of the
@@ -1802,10 +1816,16 @@ __global__ void k_unpack(const uint64_t *scanned, const uint64_t *packed, int64_
         }
     }
 }
-__global__ void k_gather_bounds(const int64_t *loc_off, const int64_t *hit_off, const int64_t *pos, int64_t *out, int np)
+constexpr size_t kRouteBytes = 4096; // MyersState::h_route: routing counts (256 ints), then the pass boundaries
+struct BoundPos { int64_t v[kNumSizeClasses + 2]; }; // first pair of every size class present, then the end
+__global__ void k_gather_bounds(const int64_t *loc_off, const int64_t *hit_off, BoundPos pos, int64_t *out, int np)
 {
-    int i = threadIdx.x;
-    if (i < np) { out[2 * i] = loc_off[pos[i]]; out[2 * i + 1] = hit_off[pos[i]]; }
+    // constant indices: a dynamically indexed by-value argument would go through scratch memory
+    int64_t p = 0;
+#pragma unroll
+    for (int t = 0; t < kNumSizeClasses + 2; t++) if (t == (int)threadIdx.x) p = pos.v[t];
+    const int i = threadIdx.x;
+    if (i < np) { out[2 * i] = loc_off[p]; out[2 * i + 1] = hit_off[p]; }
 }
 // CSR fill: end columns kept in the first-pass slots, owner pair of every location, hit list
 // loc_cap: entries the location arrays hold (the launch that runs ahead of the host's knowledge of the total)
@@ -2073,6 +2093,7 @@ void ultra_myers_free(ultra_ctx *ctx)
                       &st.hbuf, &st.raw, &st.lut, &st.u_qoff, &st.u_qlen, &st.u_toff, &st.u_tlen, &st.u_k, &st.skeys, &st.perm_d, &st.inv_d, &st.stats, &st.worktmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (st.h_route) { (void)hipHostFree(st.h_route); st.h_route = nullptr; }
     for (auto &bk : st.buckets) {
         bk.fwd_list.release(); bk.rev_list.release(); bk.fwd_flag.release();
         if (bk.ev0) { (void)hipEventDestroy(bk.ev0); bk.ev0 = nullptr; }
@@ -2540,6 +2561,18 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     }
     ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[4], s)); // all forward launches done
+    // The caller's mid-run work only needs the forward pass.  With eight lanes it goes onto the last auxiliary lane now,
+    // beside the offsets below (a chain of small kernels on an otherwise idle chip); every later join takes it back in.
+    bool hook_early = false;
+    if (ctx->mid_hook && ctx->cfg.launch_lanes == kLanes) {
+        hipStream_t hs = ctx->aux[kAuxStreams - 1];
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(ctx->fork_ev, s));
+        ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(hs, ctx->fork_ev, 0));
+        const int hrc = ctx->mid_hook(hs);
+        if (hrc != ULTRA_OK) return hrc;
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[6], hs));
+        hook_early = true;
+    }
     // ---- CSR offsets ----
     int64_t *d_overflow = st.bounds.as<int64_t>() + 48; // one flag per register bucket
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(d_overflow, 0, kBuckets * 8, s));
@@ -2568,13 +2601,20 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         int npz = (int)pos.size();
         int64_t *dpos = st.bounds.as<int64_t>();
         int64_t *dout = dpos + 64;
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(dpos, pos.data(), npz * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_gather_bounds, dim3(1), dim3(64), 0, s, st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), dpos, dout, npz);
-        std::vector<int64_t> hb((size_t)npz * 2);
-        ultra_drain_guard drain_b(ctx); // pos / hb are copy endpoints
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb.data(), dout, npz * 16, hipMemcpyDeviceToHost, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_overflow, d_overflow, kBuckets * 8, hipMemcpyDeviceToHost, s));
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_rerun, st.bounds.as<int64_t>() + 120, kBuckets * 4, hipMemcpyDeviceToHost, s));
+        if (npz > kNumSizeClasses + 2) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_myers_run: more size classes than the library knows");
+        BoundPos bp;
+        for (int t = 0; t < kNumSizeClasses + 2; t++) bp.v[t] = t < npz ? pos[(size_t)t] : 0;
+        hipLaunchKernelGGL(k_gather_bounds, dim3(1), dim3(64), 0, s, st.locoff.as<int64_t>(), st.hitoff.as<int64_t>(), bp, dout, npz);
+        // The totals land in page-locked memory: a copy into pageable memory holds the host until it has been carried out,
+        // and the launch below, which is meant to run while the totals travel, went out 0.3 ms late.
+        if (!st.h_route) ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&st.h_route, kRouteBytes, hipHostMallocDefault));
+        int64_t *hb = (int64_t *)((char *)st.h_route + 1024);
+        int64_t *p_overflow = hb + 40;
+        int32_t *p_rerun = (int32_t *)(hb + 48);
+        ultra_drain_guard drain_b(ctx);
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(hb, dout, npz * 16, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(p_overflow, d_overflow, kBuckets * 8, hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(p_rerun, st.bounds.as<int64_t>() + 120, kBuckets * 4, hipMemcpyDeviceToHost, s));
         // The location arrays are filled while the totals travel to the host, into what the arrays hold from earlier
         // batches; the host only waits for the copies (st.ev[1] serves as their marker until it is recorded for good).
         if (loc_cap > 0) {
@@ -2585,6 +2625,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             ULTRA_HIP_CHECK(ctx, hipEventSynchronize(st.ev[1]));
         } else ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         drain_b.dismiss();
+        for (int b = 0; b < kBuckets; b++) { h_overflow[b] = p_overflow[b]; h_rerun[b] = p_rerun[b]; }
         for (size_t c = 0; c < st.classes.size(); c++) {
             st.classes[c].lb = hb[2 * c]; st.classes[c].le = hb[2 * (c + 1)];
             st.classes[c].hb = hb[2 * c + 1]; st.classes[c].he = hb[2 * (c + 1) + 1];
@@ -2604,6 +2645,24 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         const int lrc = long_buffers(longc->le - longc->lb);
         if (lrc != ULTRA_OK) return lrc;
+    }
+    // ---- traceback routing, first half.  Which band class a hit goes to follows from its distance, so the per-class
+    //      counts the host lays the traceback launches out with only need the forward pass: they are taken now and have
+    //      reached the host long before the start pass ends.  What is left behind the start pass is the sort of the hits
+    //      inside their classes (by the first location's length, which needs its start): stream-ordered, no host round
+    //      trip between the two passes (before: 1.0 ms from the last start kernel to the first traceback kernel). ----
+    const int64_t n_hits = st.total_hit;
+    // the band kernels rebuild match vectors from 3 or 5 bit-planes of (code + 1): up to 31 symbols; beyond, full height
+    const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0 && st.S + 1 <= 32;
+    if (!st.h_route) ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&st.h_route, kRouteBytes, hipHostMallocDefault));
+    int32_t *const h_info = st.h_route; // page-locked: the copy must not hold the host up
+    if (use_band) {
+        ULTRA_HIP_CHECK(ctx, st.bandinfo.ensure(256));
+        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bandinfo.p, 0, 256, s));
+        hipLaunchKernelGGL(k_band_keys<true>, dim3((unsigned)std::min<int64_t>((n_hits + 255) / 256, 1024)), dim3(256), 0, s, a, n_hits, (uint32_t *)nullptr, st.bandinfo.as<int32_t>());
+        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, (kBandBounds + kBandClasses + kNumSizeClasses) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[5], s));
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare), and
@@ -2715,7 +2774,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     // The caller's mid-run work on a lane beside the traceback's routing (two chains of small kernels, the chip is
     // otherwise idle): the main stream takes it back in before the routing's copy to the host.
     bool hook_beside = false;
-    if (ctx->mid_hook) {
+    if (ctx->mid_hook && !hook_early) {
         hipStream_t hs = ctx->cfg.launch_lanes > 1 ? ctx->aux[0] : s;
         if (hs != s) {
             ULTRA_HIP_CHECK(ctx, hipEventRecord(ctx->fork_ev, s));
@@ -2729,11 +2788,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     a.ops = want_ops ? st.ops.as<uint8_t>() : nullptr;
     a.ops_off = want_ops ? st.opsoff.as<int64_t>() : nullptr;
     const size_t budget = (size_t)16 << 30; // trace scratch budget (bytes)
-    const int64_t n_hits = st.total_hit;
     int32_t h_band[2 * (kBandClasses + 1)]; // counts, then longest first location, per band class
     for (auto &v : h_band) v = 0;
-    // the band kernels rebuild match vectors from 3 or 5 bit-planes of (code + 1): up to 31 symbols; beyond, full height
-    const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0 && st.S + 1 <= 32;
     a.nw_items = nullptr;
     bool forked = false;
     bool hook_arrived = false; // a host synchronisation has followed the caller's mid-run work on s
@@ -2746,29 +2802,24 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     // behind the thousands of narrow-band wavefronts they would wait for LDS before they even start.
     std::function<int()> launch_bands = [] { return (int)ULTRA_OK; };
     if (use_band) {
-        // 3a: banded kernels for every hit whose distance fits a band of at most 512 rows
+        // 3a: banded kernels for every hit whose distance fits a band of at most 1024 rows.  Second half of the routing:
+        // the hits sorted inside their classes, behind the start pass and in front of the fork below
         const size_t NH = (size_t)n_hits;
-        ULTRA_HIP_CHECK(ctx, st.bandcls.ensure(NH + 64));
         ULTRA_HIP_CHECK(ctx, st.banditems.ensure(NH * 4 * 4)); // keys in | keys out | items out
-        ULTRA_HIP_CHECK(ctx, st.bandinfo.ensure(256));
         uint32_t *k_in = st.banditems.as<uint32_t>(), *k_out = k_in + NH;
         int32_t *items_sorted = (int32_t *)(k_out + NH);
-        const unsigned gb = (unsigned)((n_hits + 255) / 256);
-        ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bandinfo.p, 0, 256, s));
-        hipLaunchKernelGGL(k_band_keys, dim3(gb), dim3(256), 0, s, a, n_hits, k_in, st.bandinfo.as<int32_t>());
+        hipLaunchKernelGGL(k_band_keys<false>, dim3((unsigned)((n_hits + 255) / 256)), dim3(256), 0, s, a, n_hits, k_in, (int32_t *)nullptr);
         {
             size_t tmp_bytes = 0;
             ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kTbKeyBits, s));
             ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
             ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kTbKeyBits, s));
         }
-        hipLaunchKernelGGL(k_band_groups, dim3(1), dim3(64), 0, s, k_out, n_hits, st.bandinfo.as<int32_t>());
-        ULTRA_HIP_CHECK(ctx, hipGetLastError());
-        int32_t h_info[kBandBounds + kBandClasses + kNumSizeClasses];
-        if (hook_beside) { ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->join_ev[0], 0)); hook_beside = false; }
-        ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, sizeof h_info, hipMemcpyDeviceToHost, s));
-        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
-        hook_arrived = true;
+        ULTRA_HIP_CHECK(ctx, hipEventSynchronize(st.ev[5])); // the counts: on the host since the start pass began
+        {   // hits per group -> first sorted position of every group, then the end
+            int32_t acc = 0;
+            for (int g = 0; g < kBandBounds; g++) { const int32_t c = g < kBandBounds - 1 ? h_info[g] : 0; h_info[g] = acc; acc += c; }
+        }
         int32_t band_first[kBandClasses + 1];
         for (int c = 0; c <= kBandClasses; c++) band_first[c] = h_info[c];
         for (int c = 0; c < kBandClasses; c++) {
@@ -2825,24 +2876,26 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             const int WB = band_words(c);
             const size_t band_lds = (size_t)band_chunk(c) * band_rows(c) * 16; // K columns x {Pv, Ph} of the window per lane
             if (c >= 3) {
-                const size_t glds = (size_t)8 * (c == 6 ? 3 : 2) * 64 * 16; // K columns x WBL words x 64 lanes x {Pv, Ph}
+                const size_t glds = (size_t)8 * (band_words(c) / band_group(c)) * 64 * 16; // K columns x WBL words x 64 lanes x {Pv, Ph}
+#define ULTRA_BANDG(C, NPV) hipLaunchKernelGGL((myers_bandg<band_group(C), band_words(C) / band_group(C), NPV>), grid, block, glds, cs, b, items, ni)
                 if (np == 3) {
                     switch (c) {
-                    case 3: hipLaunchKernelGGL((myers_bandg<2, 2, 3>), grid, block, glds, cs, b, items, ni); break;
-                    case 4: hipLaunchKernelGGL((myers_bandg<3, 2, 3>), grid, block, glds, cs, b, items, ni); break;
-                    case 5: hipLaunchKernelGGL((myers_bandg<4, 2, 3>), grid, block, glds, cs, b, items, ni); break;
-                    case 6: hipLaunchKernelGGL((myers_bandg<4, 3, 3>), grid, block, glds, cs, b, items, ni); break;
-                    default: hipLaunchKernelGGL((myers_bandg<8, 2, 3>), grid, block, glds, cs, b, items, ni); break;
+                    case 3: ULTRA_BANDG(3, 3); break;
+                    case 4: ULTRA_BANDG(4, 3); break;
+                    case 5: ULTRA_BANDG(5, 3); break;
+                    case 6: ULTRA_BANDG(6, 3); break;
+                    default: ULTRA_BANDG(7, 3); break;
                     }
                 } else {
                     switch (c) {
-                    case 3: hipLaunchKernelGGL((myers_bandg<2, 2, 5>), grid, block, glds, cs, b, items, ni); break;
-                    case 4: hipLaunchKernelGGL((myers_bandg<3, 2, 5>), grid, block, glds, cs, b, items, ni); break;
-                    case 5: hipLaunchKernelGGL((myers_bandg<4, 2, 5>), grid, block, glds, cs, b, items, ni); break;
-                    case 6: hipLaunchKernelGGL((myers_bandg<4, 3, 5>), grid, block, glds, cs, b, items, ni); break;
-                    default: hipLaunchKernelGGL((myers_bandg<8, 2, 5>), grid, block, glds, cs, b, items, ni); break;
+                    case 3: ULTRA_BANDG(3, 5); break;
+                    case 4: ULTRA_BANDG(4, 5); break;
+                    case 5: ULTRA_BANDG(5, 5); break;
+                    case 6: ULTRA_BANDG(6, 5); break;
+                    default: ULTRA_BANDG(7, 5); break;
                     }
                 }
+#undef ULTRA_BANDG
             } else if (c == 0) {
                 if (np == 3) hipLaunchKernelGGL((myers_band32<3>), grid, block, band_lds, cs, b, items, ni);
                 else hipLaunchKernelGGL((myers_band32<5>), grid, block, band_lds, cs, b, items, ni);
@@ -2937,6 +2990,10 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     }
     if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[3], s));
+    if (hook_early) { // joined into s with the start pass; its copies have landed once its event has
+        ULTRA_HIP_CHECK(ctx, hipEventSynchronize(st.ev[6]));
+        hook_arrived = true;
+    }
     if (defer_sync && hook_arrived) {
         st.times_pending = true;
         drain.dismiss();
