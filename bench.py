@@ -396,6 +396,40 @@ def main():
                 ms_acc = [a + b for a, b in zip(ms_acc, r["ms"])]
         secs = time.perf_counter() - t0
         n_calls = args.front_rounds * len(pbs)
+        # two workers (each its own context and front object, half the host threads) on alternate batches: one's parsing and
+        # selection run beside the other's device work
+        two_rate = None
+        try:
+            import threading
+            half = max(1, min(16, len(os.sched_getaffinity(0))) // 2)
+            ctx2 = ctxs[1] if len(ctxs) > 1 else lib.Context(local, cfg=cfg or None)
+            frs = [front_mod.Front(ctxs[0], dix, nix, {c: 200000 for c in range(wkw["n_chr"])}, n_threads=half),
+                   front_mod.Front(ctx2, dix, nix, {c: 200000 for c in range(wkw["n_chr"])}, n_threads=half)]
+            for f, pb in zip(frs, pbs):
+                f.run(pb, *prm, copy=False)
+            rounds2 = max(2, args.front_rounds)
+            errs = []
+
+            def worker(f, pb):
+                try:
+                    for _ in range(rounds2):
+                        f.run(pb, *prm, copy=False)
+                except Exception as e:      # noqa: BLE001
+                    errs.append(e)
+            ths = [threading.Thread(target=worker, args=(f, pb)) for f, pb in zip(frs, pbs)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            two_s = time.perf_counter() - t0
+            if errs:
+                raise errs[0]
+            two_rate = args.reads * rounds2 * len(frs) / two_s
+            for f in frs:
+                f.close()
+        except Exception as e:              # noqa: BLE001
+            two_rate = "failed: %r" % (e,)
         t0 = time.perf_counter()
         res = fr.run(pbs[0], *prm)                       # the same with every array copied out into numpy
         numpy_s = time.perf_counter() - t0
@@ -418,6 +452,7 @@ def main():
                              % (args.reads, pbs[0].text.size / float(args.reads), min(16, len(os.sched_getaffinity(0)))),
                      "ms_per_batch": {k: v / n_calls for k, v in zip(("parse_bounds", "nam_chaining", "selection", "stage", "run", "fetch"), ms_acc)},
                      "locations_per_read": n_loc / float(args.reads * n_calls),
+                     "two_workers_reads_per_s": two_rate,
                      "with_numpy_copies_reads_per_s": args.reads / numpy_s,
                      "python_tuple_us_per_location_on_access": tuple_us,
                      "python_shims_us_per_read_phases_1_to_3": py_us}

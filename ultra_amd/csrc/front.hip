@@ -44,6 +44,33 @@ struct RawBytes {
     }
 };
 
+// An array the device copies from or into: page-locked (a copy from pageable memory goes through a staging buffer at a
+// third of the rate), grown without keeping its contents (every user writes what it reads), ordinary memory when the
+// runtime refuses.  Only the members the code below uses on std::vector.
+template <typename T> struct HostBuf {
+    T *p = nullptr; size_t n = 0; bool locked = false;
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf() { release(); }
+    void release() { if (p) { if (locked) (void)hipHostFree(p); else free(p); } p = nullptr; n = 0; locked = false; }
+    size_t size() const { return n; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void resize(size_t m)
+    {
+        if (m <= n) return;
+        release();
+        void *q = nullptr;
+        if (hipHostMalloc(&q, m * sizeof(T), hipHostMallocDefault) == hipSuccess) locked = true;
+        else { (void)hipGetLastError(); q = malloc(m * sizeof(T)); }
+        if (!q) throw std::bad_alloc();
+        p = (T *)q; n = m;
+    }
+};
+
 struct Part { // what one worker thread produced for its range of reads (copied to its place in read order afterwards)
     std::vector<Nam> nams;          // instance after instance, in the read's processing order
     std::vector<Inst> insts;        // first = position in this part's nams
@@ -218,13 +245,14 @@ struct ultra_front {
     std::vector<uint8_t> loc_rc;
     std::vector<int64_t> loc_score;
     // phase 4: the plan request and the MAM stage's results
-    std::vector<int64_t> rq_nam_off, rq_part, rq_x, rq_y, rq_read_off;
+    // what travels to and from the device lies in page-locked memory (HostBuf)
+    HostBuf<int64_t> rq_nam_off, rq_part, rq_x, rq_y, rq_read_off;
     std::vector<int32_t> sol_c, sol_d, sol_j;
-    std::vector<uint8_t> rq_reads;
-    std::vector<double> m_value, m_cval;
-    std::vector<int32_t> m_nmam, m_cx, m_cy, m_cc, m_cd, m_msl, m_cand, m_cj, m_cchr;
-    std::vector<int64_t> m_chain_off;
-    std::vector<uint8_t> m_ckind;
+    HostBuf<uint8_t> rq_reads;
+    HostBuf<double> m_value, m_cval;
+    HostBuf<int32_t> m_nmam, m_cx, m_cy, m_cc, m_cd, m_msl, m_cand, m_cj, m_cchr;
+    HostBuf<int64_t> m_chain_off;
+    HostBuf<uint8_t> m_ckind;
     float ms[6] = {0, 0, 0, 0, 0, 0};
     int64_t n_quadratic = 0, n_nlogn = 0;
 };
@@ -565,7 +593,14 @@ int ultra_front_run(ultra_front *f, ultra_ctx *ctx, const ultra_dindex *dix, con
     rq.n_inst = (int32_t)f->n_loc;
     rq.inst_nam_off = f->rq_nam_off.data(); rq.nam_part = f->rq_part.data(); rq.nam_x = f->rq_x.data(); rq.nam_y = f->rq_y.data();
     rq.reads = f->rq_reads.data(); rq.read_off = f->rq_read_off.data();
-    rc = ultra_mam_stage_nams(ctx, dix, &rq);
+    {
+        static const bool trace = getenv("ULTRA_FRONT_TRACE") != nullptr; // development aid: where the stage time goes
+        const double u0 = now_ms();
+        rc = ultra_mam_upload_nams(ctx, &rq);
+        const double u1 = now_ms();
+        if (rc == ULTRA_OK) rc = ultra_mam_plan_resident(ctx, dix);
+        if (trace) fprintf(stderr, "ultra_front: upload %.2f ms (page-locked: %d), plan %.2f ms\n", u1 - u0, (int)f->rq_reads.locked, now_ms() - u1);
+    }
     if (rc == ULTRA_E_UNSUPPORTED && ix) { // an instance beyond the device planner's envelope: plan this batch on the host
         ultra_plan *pl = nullptr;
         rc = ultra_plan_create(ix, &rq, &pl);
