@@ -77,6 +77,10 @@ def parse_args():
     ap.add_argument("--overlap", type=int, default=1,
                     help="host threads of the timed loop (measured: no gain, the GPU is the bottleneck either way): 2 = the enumeration of the next batch rides beside the kernels of the current "
                          "one (two contexts, runs serialised), 1 = plan and run one after the other")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="timed region: 1 = one host thread, the planner of batch i + 1 behind the start pass of batch i's run (ultra_mam_run_begin / "
+                         "_plan_resident_behind / _run_end; measured 1.5 %% faster, but the planner then runs inside the tail's stage timers); "
+                         "0 = plan and run strictly one after the other, and the pipelined loop is an extra leg behind the timed region")
     ap.add_argument("--front-rounds", type=int, default=2, help="passes over two batches through the native front end (0 = skip)")
     ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
     ap.add_argument("--micro-scale", type=float, default=1.0, help="fraction of the micro-benchmarks' pair counts")
@@ -241,13 +245,29 @@ def main():
     ctxs[0].mam_stage_nams(dix, sets[0].nam_off, sets[0].nam_part, sets[0].nam_x, sets[0].nam_y, sets[0].reads, sets[0].read_off)
     restage_ms = (time.perf_counter() - t0) * 1e3
     ctxs[0].mam_run(P["min_acc"])
-    class_ms = {}
-    acc = {"fwd": 0.0, "rev": 0.0, "tb": 0.0, "all": 0.0, "fwdk": 0.0, "build": 0.0, "chain": 0.0, "gather": 0.0}
     import threading
-    tot = {"cells_run": 0.0, "cells_skip": 0.0, "pairs_skip": 0.0, "plan_s": 0.0, "run_s": 0.0}
     run_lock = threading.Lock()      # a run fills the chip: one at a time; the other thread's enumeration rides beside it
     n_thr = max(1, min(args.overlap, nb))
     errors = []
+
+    def new_acc():
+        return ({}, {"fwd": 0.0, "rev": 0.0, "tb": 0.0, "all": 0.0, "fwdk": 0.0, "build": 0.0, "chain": 0.0, "gather": 0.0},
+                {"cells_run": 0.0, "cells_skip": 0.0, "pairs_skip": 0.0, "plan_s": 0.0, "run_s": 0.0})
+
+    def collect(c, class_ms, acc, tot):
+        cells, ms = c.myers_timing()
+        tot["cells_run"] += cells
+        sk = c.myers_cell_counts()
+        tot["cells_skip"] += sk[1]; tot["pairs_skip"] += sk[2]
+        acc["fwd"] += ms[0]; acc["rev"] += ms[1]; acc["tb"] += ms[2]; acc["all"] += ms[3]; acc["fwdk"] += ms[4]
+        mm = c.mam_timing()
+        acc["build"] += mm[0]; acc["chain"] += mm[1]; acc["gather"] += mm[2]
+        for key, (cc, t) in c.myers_class_timing().items():
+            a = class_ms.setdefault(key, [0.0, 0.0, 0])
+            a[0] += cc; a[1] += t; a[2] += 1
+
+    class_ms, acc, tot = new_acc()
+    host_ms = {"run_begin": 0.0, "plan_behind": 0.0, "run_end": 0.0}   # where the pipelined loop's host thread spends a step
 
     def steps_of(tid):
         try:
@@ -261,23 +281,45 @@ def main():
                     c.mam_run(P["min_acc"])
                     tot["run_s"] += time.perf_counter() - t3
                     tot["plan_s"] += t2 - t1
-                    cells, ms = c.myers_timing()
-                    tot["cells_run"] += cells
-                    sk = c.myers_cell_counts()
-                    tot["cells_skip"] += sk[1]; tot["pairs_skip"] += sk[2]
-                    acc["fwd"] += ms[0]; acc["rev"] += ms[1]; acc["tb"] += ms[2]; acc["all"] += ms[3]; acc["fwdk"] += ms[4]
-                    mm = c.mam_timing()
-                    acc["build"] += mm[0]; acc["chain"] += mm[1]; acc["gather"] += mm[2]
-                    for key, (cc, t) in c.myers_class_timing().items():
-                        a = class_ms.setdefault(key, [0.0, 0.0, 0])
-                        a[0] += cc; a[1] += t; a[2] += 1
+                    collect(c, class_ms, acc, tot)
         except Exception as e:      # noqa: BLE001 - reported by the main thread
             errors.append(e)
+
+    def steps_pipelined(class_ms, acc, tot, host_ms):
+        # One host thread, consecutive batches pipelined on the device: the run of batch i is enqueued as a whole
+        # (ultra_mam_run_begin returns once the forward pass's counts are on the host), then the planner of batch i + 1 goes
+        # out on its own context, ordered behind that run's start pass: it shares the chip with the run's latency-bound tail
+        # (traceback, MAM build, chaining), not with the passes that fill it.  K plans and K runs inside the timed region;
+        # the first plan has nothing to ride under.
+        ctxs[0].mam_plan_resident(dix)
+        for i in range(args.steps):
+            c = ctxs[i % nb]
+            t3 = time.perf_counter()
+            c.mam_run_begin(P["min_acc"])
+            t4 = time.perf_counter()
+            if i + 1 < args.steps:
+                ctxs[(i + 1) % nb].mam_plan_resident_behind(dix, c)
+            t5 = time.perf_counter()
+            c.mam_run_end()
+            t6 = time.perf_counter()
+            tot["run_s"] += t6 - t3
+            host_ms["run_begin"] += (t4 - t3) * 1e3; host_ms["plan_behind"] += (t5 - t4) * 1e3; host_ms["run_end"] += (t6 - t5) * 1e3
+            collect(c, class_ms, acc, tot)
+
     if nb % n_thr:
         n_thr = 1
+    pipelined = bool(args.pipeline) and n_thr == 1 and nb >= 2
+    if pipelined:       # the warm-up of this loop's shape: the contexts have met every buffer size already, the streams have not met each other
+        for i in range(min(args.warmup, 2)):
+            ctxs[i % nb].mam_plan_resident(dix)
+            ctxs[i % nb].mam_run_begin(P["min_acc"])
+            ctxs[(i + 1) % nb].mam_plan_resident_behind(dix, ctxs[i % nb])
+            ctxs[i % nb].mam_run_end()
     barrier()
     t0 = time.perf_counter()
-    if n_thr == 1:
+    if pipelined:
+        steps_pipelined(class_ms, acc, tot, host_ms)
+    elif n_thr == 1:
         steps_of(0)
     else:
         ths = [threading.Thread(target=steps_of, args=(t,)) for t in range(n_thr)]
@@ -289,6 +331,40 @@ def main():
     elapsed = time.perf_counter() - t0
     if errors:
         raise errors[0]
+    # ---- the same steps one after the other (plan, then run; nothing overlaps): the parts by themselves ----
+    seq_class, seq_acc, seq_tot = new_acc()
+    n_seq = nb if pipelined else 0
+    t0 = time.perf_counter()
+    for i in range(n_seq):
+        c = ctxs[i % nb]
+        t1 = time.perf_counter()
+        c.mam_plan_resident(dix)
+        t2 = time.perf_counter()
+        c.mam_run(P["min_acc"])
+        seq_tot["run_s"] += time.perf_counter() - t2
+        seq_tot["plan_s"] += t2 - t1
+        collect(c, seq_class, seq_acc, seq_tot)
+    seq_elapsed = time.perf_counter() - t0
+    pipe_leg = None
+    if not pipelined:
+        seq_acc, seq_tot, n_seq, seq_elapsed = acc, tot, args.steps, elapsed
+        if n_thr == 1 and nb >= 2 and world == 1:
+            # the pipelined loop as an extra leg (not `value`): its planner runs inside the tail's stage timers
+            _, p_acc, p_tot = new_acc()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            steps_pipelined({}, p_acc, p_tot, host_ms)
+            torch.cuda.synchronize()
+            p_el = time.perf_counter() - t0
+            pipe_leg = {"ms_per_step": p_el / args.steps * 1e3, "reads_per_s": args.reads * args.steps / p_el, "steps": args.steps,
+                        "host_ms_per_step": {k: v / args.steps for k, v in host_ms.items()},
+                        "stage_ms_per_step": {"myers_forward": p_acc["fwd"] / args.steps, "myers_starts": p_acc["rev"] / args.steps,
+                                              "myers_traceback": p_acc["tb"] / args.steps, "mam_build": p_acc["build"] / args.steps,
+                                              "chain": p_acc["chain"] / args.steps},
+                        "note": "ultra_mam_run_begin(i) -> ultra_mam_plan_resident_behind(i + 1) -> ultra_mam_run_end(i) on one host thread: the "
+                                "planner of the next batch shares the chip with the run's traceback, MAM build and chaining.  Both slow "
+                                "down (the tail is not idle, it is short of wavefront slots): a little faster than plan-then-run, "
+                                "not by the planner's 4 ms"}
     cells_run, cells_skip, pairs_skip, plan_s, run_s = (tot[k] for k in ("cells_run", "cells_skip", "pairs_skip", "plan_s", "run_s"))
     K = args.steps
     elapsed, reads_all, cells_all = shard.reduce_job(elapsed, args.reads * K, cells_run, device=red_dev)
@@ -373,7 +449,7 @@ def main():
                "output": "chains with kind / chromosome in pinned host memory", "per_batch_ms": ms_pin,
                "pageable_input": {"reads_per_s": rate_pg, "per_batch_ms": ms_pg},
                "chain_rows_fetched": chains,
-               "synchronous_caller_reads_per_s": args.reads / ((restage_ms + run_max / K * 1e3 + fetch_s * 1e3) * 1e-3)}
+               "synchronous_caller_reads_per_s": args.reads / ((restage_ms + seq_tot["run_s"] / max(n_seq, 1) * 1e3 + fetch_s * 1e3) * 1e-3)}
 
     # ---- the per-read host steps in front of the MAM stage (align.py:427-489), natively: seed text -> SAM-ready arrays ----
     front_leg = None
@@ -541,13 +617,29 @@ def main():
                        **({"rehearsal": "all ranks share GPU 0, gloo rendezvous: the path is exercised, the value is not a measurement"} if args.rehearse else {})},
             "myers_gcups_forward": cells_all / (acc["fwd"] * 1e-3) * 1e-9 / world if acc["fwd"] > 0 else None,
             "myers_gcups_all_passes": cells_all / (acc["all"] * 1e-3) * 1e-9 / world if acc["all"] > 0 else None,
-            "kernels_only": {"reads_per_s": reads_all / run_max, "ms_per_step": run_max / K * 1e3,
-                             "note": "ultra_mam_run alone (candidates and sorted pairs already staged): what round 2 reported as value"},
-            "plan_ms_per_step": plan_s / K * 1e3,
+            "kernels_only": {"reads_per_s": args.reads * n_seq / seq_tot["run_s"] if seq_tot["run_s"] > 0 else None,
+                             "ms_per_step": seq_tot["run_s"] / max(n_seq, 1) * 1e3,
+                             "note": "ultra_mam_run alone (candidates and sorted pairs already staged), nothing beside it: what round 2 reported as value"},
+            "plan_ms_per_step": seq_tot["plan_s"] / max(n_seq, 1) * 1e3,
+            "sequential": {"ms_per_step": seq_elapsed / max(n_seq, 1) * 1e3, "reads_per_s": args.reads * n_seq / seq_elapsed if seq_elapsed > 0 else None,
+                           "steps": n_seq,
+                           "note": "plan, then run, nothing overlapping (after the timed region; round 3's first value); plan_ms_per_step, "
+                                   "kernels_only and stage_ms_sequential are its parts",
+                           "stage_ms_per_step": {"myers_forward": seq_acc["fwd"] / max(n_seq, 1), "myers_starts": seq_acc["rev"] / max(n_seq, 1),
+                                                 "myers_traceback": seq_acc["tb"] / max(n_seq, 1), "myers_total": seq_acc["all"] / max(n_seq, 1),
+                                                 "mam_build": seq_acc["build"] / max(n_seq, 1), "chain": seq_acc["chain"] / max(n_seq, 1),
+                                                 "chain_gather": seq_acc["gather"] / max(n_seq, 1)}},
             "host_threads": n_thr,
-            "overlap_note": "with 2 host threads the enumeration + pair sort of batch i + 1 (its own context) runs beside the kernels of "
-                            "batch i; runs are serialised.  ms_per_step = wall time / steps; plan_ms_per_step and kernels_only are the two "
-                            "parts as their threads saw them (they overlap, so they add up to more than ms_per_step)",
+            "pipelined": pipelined,
+            "pipelined_host_ms_per_step": {k: v / K for k, v in host_ms.items()} if pipelined else None,
+            "pipelined_leg": pipe_leg,
+            "overlap_note": "timed region: one host thread; the run of batch i is enqueued as a whole (ultra_mam_run_begin), the planner of "
+                            "batch i + 1 (its own context) is ordered behind that run's start pass and shares the chip with its traceback, "
+                            "MAM build and chaining (ultra_mam_plan_resident_behind), then ultra_mam_run_end.  K plans + K runs in the timed "
+                            "region; stage_ms_per_step are the timed region's own event timers (the tail's stages are longer than in "
+                            "`sequential` because the planner runs beside them)" if pipelined else
+                            "plan and run one after the other" if n_thr == 1 else
+                            "2 host threads: the enumeration + pair sort of batch i + 1 (its own context) beside the kernels of batch i, uncoordinated",
             "stage_ms_per_step": {"myers_forward": acc["fwd"] / K, "myers_starts": acc["rev"] / K, "myers_traceback": acc["tb"] / K,
                                   "myers_total": acc["all"] / K, "mam_build": acc["build"] / K, "chain": acc["chain"] / K,
                                   "chain_gather": acc["gather"] / K},

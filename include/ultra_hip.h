@@ -287,6 +287,13 @@ int ultra_mam_batch(ultra_ctx *ctx, const ultra_mam_input *in, double min_acc, u
  * After _run, ultra_mam_sizes gives the sizes _fetch needs (sum of chain lengths, sum of n_mam). */
 int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in);
 int ultra_mam_run(ultra_ctx *ctx, double min_acc);
+/* ultra_mam_run in two halves, for a caller that pipelines consecutive batches (the reference overlaps reads by running
+ * nr_cores workers, modules/pc.py:78-83; here the overlap is between a run's tail and the next batch's planner).
+ * _run_begin returns when the whole run has been ENQUEUED - the host has waited for the forward pass only; the start pass,
+ * the traceback, the MAM build and the chainers are still in flight - and _run_end waits for the device and closes the run.
+ * Between the two nothing of this context may be touched; ultra_mam_run = _run_begin + _run_end. */
+int ultra_mam_run_begin(ultra_ctx *ctx, double min_acc);
+int ultra_mam_run_end(ultra_ctx *ctx);
 int ultra_mam_sizes(const ultra_ctx *ctx, int64_t *n_chain_total, int64_t *n_mam_total);
 int ultra_mam_fetch(ultra_ctx *ctx, ultra_mam_output *out);
 /* Device milliseconds of the last _run beyond the Myers passes (ultra_myers_last_timing):
@@ -372,6 +379,12 @@ int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dix, const ultra_pl
  * request survives ultra_mam_run / _fetch and can be planned again; ultra_myers_stage / ultra_mam_stage replace it. */
 int ultra_mam_upload_nams(ultra_ctx *ctx, const ultra_plan_request *rq);
 int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dix);
+/* _plan_resident with its kernels ordered (on the device) behind the start pass of the run that `front`, another context
+ * of the same GPU, has in flight (ultra_mam_run_begin, or ultra_mam_run on another thread: the call then first waits until
+ * that run has enqueued its start pass).  The forward and start passes fill the chip, the rest of a run is latency-bound:
+ * the planner of batch i + 1 rides under the tail of batch i.  With no run in flight on `front` (or front == NULL) it is
+ * ultra_mam_plan_resident.  Results are those of ultra_mam_plan_resident. */
+int ultra_mam_plan_resident_behind(ultra_ctx *ctx, const ultra_dindex *dix, ultra_ctx *front);
 /* device copies of the staged batch's candidate arrays, for tests that compare the two planners: any pointer may be
  * NULL; capacities are the counts ultra_mam_counts reports */
 int ultra_mam_counts(const ultra_ctx *ctx, int32_t *n_inst, int32_t *n_cand, int32_t *n_pairs);

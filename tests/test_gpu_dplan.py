@@ -142,3 +142,61 @@ def test_device_plan_big_instances_and_errors(ctx):
         assert all(_same(a, b) for a, b in zip(again, got[:2]))
     finally:
         dix.close(); ix.close()
+
+
+def test_pipelined_batches_equal_plain_runs(ctx):
+    """ultra_mam_run_begin / ultra_mam_plan_resident_behind / ultra_mam_run_end: three batches on two contexts, the
+    planner of batch i + 1 enqueued behind the start pass of batch i's run, give the results of plain plan + run
+    (and of the oracle); state errors are reported, and an empty batch neither blocks nor breaks the chain."""
+    from oracle import classify_port
+    from ultra_amd import classify_read_with_mams as stage
+    from ultra_amd import index as native
+    from ultra_amd import lib, synth
+    w = synth.make_world(seed=77, n_genes=80, n_chr=2)
+    idx = w.index()
+    batches = []
+    for b, n in enumerate((300, 0, 170, 260)):
+        insts = synth.make_instances(w, n, seed=40 + b, preset="ont_cdna", flank_start_prob=0.3, flank_end_prob=0.3) if n else []
+        batches.append((insts, native.flatten_instances([(sol, read) for read, sol, _ in insts])))
+    ix = native.NativeIndex(*idx)
+    dix = native.DeviceIndex(ix)
+    other = lib.Context(0)
+    cs = [ctx, other]
+    try:
+        want = []
+        for insts, flat in batches:
+            ctx.mam_stage_nams(dix, *flat)
+            ctx.mam_run(0.6)
+            want.append(stage.results_from_names(ctx.mam_fetch(want_names=True), np.diff(flat[5]).tolist()))
+        with pytest.raises(lib.UltraError):
+            ctx.mam_run_end()                       # nothing in flight
+        got = [None] * len(batches)
+        cs[0].mam_stage_nams(dix, *batches[0][1], upload_only=True)
+        cs[0].mam_plan_resident(dix)
+        for i, (insts, flat) in enumerate(batches):
+            c, nxt = cs[i % 2], cs[(i + 1) % 2]
+            c.mam_run_begin(0.6)
+            with pytest.raises(lib.UltraError):
+                c.mam_run_begin(0.6)                # the run in flight has not been closed
+            if i + 1 < len(batches):
+                nxt.mam_stage_nams(dix, *batches[i + 1][1], upload_only=True)
+                nxt.mam_plan_resident_behind(dix, c)
+            c.mam_run_end()
+            got[i] = stage.results_from_names(c.mam_fetch(want_names=True), np.diff(flat[5]).tolist())
+        # behind a context with no run in flight it is the plain planner
+        cs[1].mam_stage_nams(dix, *batches[0][1], upload_only=True)
+        cs[1].mam_plan_resident_behind(dix, cs[0])
+        cs[1].mam_run(0.6)
+        again = stage.results_from_names(cs[1].mam_fetch(want_names=True), np.diff(batches[0][1][5]).tolist())
+    finally:
+        other.close(); dix.close(); ix.close()
+    for g, w_ in zip(got, want):
+        assert len(g) == len(w_)
+        for a, b in zip(g, w_):
+            assert _same(a, b)
+    for a, b in zip(again, want[0]):
+        assert _same(a, b)
+    insts = batches[0][0]
+    for i in range(0, len(insts), 9):
+        read, sol, _ = insts[i]
+        assert _same(classify_port.classify(sol, *idx, read, None, 0.6), got[0][i])

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -106,7 +108,10 @@ struct MamState {
     std::vector<int32_t> h_nmam;
     bool nmam_on_host = false;       // h_nmam holds the last run's counts (read back only when something needs them)
     int64_t *pinned_base = nullptr;  // pinned copy of instbase (first MAM slot of every instance, then the total), read
-    size_t pinned_cap = 0;           // back while the Myers passes still run; entries
+    size_t pinned_cap = 0;           // back while the Myers passes still run; entries.  The three words behind the total take
+                                     // the run's closing counts (chain rows, MAMs, chainer status): ultra_mam_run_end reads them
+    bool begun = false;              // ultra_mam_run_begin has enqueued a run that ultra_mam_run_end has not closed yet
+    bool exact_needed = false;       // that run read the exact MAM counts back (h_nmam is current)
     std::vector<int32_t> h_slots;    // slots per instance = upper bound of its MAM count
     bool up_valid = false;           // an uploaded request (ultra_mam_upload_nams) lies in d_nam* / my.raw
     int32_t up_ni = 0;
@@ -148,6 +153,14 @@ struct ultra_ctx {
     // enqueued by the Myers run on the stream it names, right after the start pass has been launched: work of the caller
     // that only needs the forward results rides under the remaining passes and shares their next host synchronisation
     std::function<int(hipStream_t)> mid_hook;
+    // How far the enqueueing of a run in flight has come.  Another context's planner (ultra_mam_plan_resident_behind)
+    // orders its kernels behind this run's start pass (my.ev[2]): they then share the chip with the latency-bound tail of
+    // the run (traceback, MAM build, chaining) instead of crawling beside the forward and start passes, which fill it.
+    std::mutex tail_mu;
+    std::condition_variable tail_cv;
+    bool run_active = false;     // between ultra_mam_run_begin and the end of ultra_mam_run_end
+    bool tail_open = false;      // the start pass of that run has been enqueued (or the run has none)
+    bool tail_has_event = false; // ... and my.ev[2] marks its end on the device
     ultra_cfg cfg;
     std::string err;
     hipDeviceProp_t prop;

@@ -969,6 +969,25 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     return ULTRA_OK;
 }
 
+// The same, with the planner's kernels ordered behind the start pass of the run that `front` (another context of the same
+// GPU) has in flight.  The forward and start passes fill the chip: a planner launched beside them crawls and slows them
+// down; the rest of a run (traceback, MAM build, chaining) is bound by latency and leaves the ALUs to a neighbour.  If
+// `front` is inside ultra_mam_run_begin on another thread, the call first waits until that run's start pass has been
+// enqueued; with no run in flight on `front` it is ultra_mam_plan_resident.
+extern "C" int ultra_mam_plan_resident_behind(ultra_ctx *ctx, const ultra_dindex *dx, ultra_ctx *front)
+{
+    if (!ctx || !dx) return ULTRA_E_ARG;
+    if (front && front != ctx && front->device == ctx->device) {
+        std::unique_lock<std::mutex> lk(front->tail_mu);
+        front->tail_cv.wait(lk, [&] { return !front->run_active || front->tail_open; });
+        if (front->run_active && front->tail_has_event) {
+            ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+            ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, front->my.ev[2], 0));
+        }
+    }
+    return ultra_mam_plan_resident(ctx, dx);
+}
+
 extern "C" int ultra_mam_stage_nams(ultra_ctx *ctx, const ultra_dindex *dx, const ultra_plan_request *rq)
 {
     if (!ctx || !dx || !rq) return ULTRA_E_ARG;

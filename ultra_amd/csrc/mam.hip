@@ -482,18 +482,28 @@ extern "C" int ultra_mam_stage(ultra_ctx *ctx, const ultra_mam_input *in)
     return ULTRA_OK;
 }
 
-extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
+namespace {
+
+void tail_state(ultra_ctx *ctx, bool active, bool open, bool has_event)
 {
-    if (!ctx) return ULTRA_E_ARG;
+    {
+        std::lock_guard<std::mutex> lk(ctx->tail_mu);
+        ctx->run_active = active; ctx->tail_open = open; ctx->tail_has_event = has_event;
+    }
+    ctx->tail_cv.notify_all();
+}
+
+// Everything of a run is enqueued; what is left for mam_run_finish is the last synchronisation and the closing counts.
+int mam_run_enqueue(ultra_ctx *ctx, double min_acc)
+{
     MamState &m = ctx->mam;
-    if (!m.staged || !ctx->my.staged) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_run: no staged batch");
     m.ran = false;
     m.total_cap = m.total_chain = m.total_mam = 0;
     for (auto &v : m.ms) v = 0;
     const int32_t nc = m.n_cand, ni = m.n_inst;
     MyersState &my = ctx->my;
     hipStream_t s = ctx->stream;
-    if (m.pinned_cap < (size_t)ni + 1) {
+    if (m.pinned_cap < (size_t)ni + 1 + 3) {
         if (m.pinned_base) { (void)hipHostFree(m.pinned_base); m.pinned_base = nullptr; m.pinned_cap = 0; }
         ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&m.pinned_base, ((size_t)ni + 1 + 64) * 8, hipHostMallocDefault));
         m.pinned_cap = (size_t)ni + 1 + 64;
@@ -526,10 +536,7 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     if (rc != ULTRA_OK) return rc;
     ultra_drain_guard drain(ctx);
     if (ni == 0) {
-        ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
-        if (my.times_pending) { const int trc = ultra_myers_collect_times(ctx); if (trc != ULTRA_OK) return trc; }
         drain.dismiss();
-        m.ran = true;
         return ULTRA_OK;
     }
     ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -578,14 +585,14 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     m.h_nmam.resize((size_t)ni);
     m.h_slots.resize((size_t)ni);
     for (int32_t i = 0; i < ni; i++) m.h_slots[(size_t)i] = (int32_t)(m.pinned_base[i + 1] - m.pinned_base[i]);
-    bool exact_needed = false;
+    m.exact_needed = false;
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[2], s));
     int32_t *d_status = nullptr;
     rc = ultra_chain_launch(ctx, ni, m.h_slots.data(), m.instbase.as<int64_t>(), m.nmam.as<int32_t>(),
                             a.mx, a.my, a.mc, a.md, a.mval,
                             0, -1, -1, m.chainidx.as<int32_t>(), m.chainlen.as<int32_t>(), m.value.as<double>(), &d_status, nullptr, nullptr, true);
     if (rc == kChainNeedExact) {
-        exact_needed = true;
+        m.exact_needed = true;
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(m.h_nmam.data(), m.nmam.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[2], s));
@@ -609,27 +616,85 @@ extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
     hipLaunchKernelGGL(k_chain_gather, dim3((ni + 3) / 4), dim3(256), 0, s, g);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[4], s));
-    int64_t h_total = 0, h_mams = 0;
-    int32_t status = 0;
     // the scan above is done with its scratch by now (stream order): its first word takes the MAM total
     hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(1024), 0, s, m.nmam.as<int32_t>(), ni, m.scantmp.as<int64_t>());
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_total, m.chainoff.as<int64_t>() + ni, 8, hipMemcpyDeviceToHost, s));
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_mams, m.scantmp.p, 8, hipMemcpyDeviceToHost, s));
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
-    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    // the closing counts land in page-locked memory behind the slot offsets (a copy into pageable memory would hold the
+    // host here until the whole run has been carried out)
+    int64_t *h_close = m.pinned_base + (size_t)ni + 1;
+    h_close[0] = h_close[1] = h_close[2] = 0;
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_close[0], m.chainoff.as<int64_t>() + ni, 8, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_close[1], m.scantmp.p, 8, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_close[2], d_status, 4, hipMemcpyDeviceToHost, s));
+    drain.dismiss();
+    return ULTRA_OK;
+}
+
+int mam_run_finish(ultra_ctx *ctx)
+{
+    MamState &m = ctx->mam;
+    MyersState &my = ctx->my;
+    const int32_t ni = m.n_inst;
+    ultra_drain_guard drain(ctx);
+    ULTRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (my.times_pending) { const int trc = ultra_myers_collect_times(ctx); if (trc != ULTRA_OK) return trc; }
-    m.total_mam = h_mams;
-    m.nmam_on_host = exact_needed; // otherwise the counts are copied when a fetch asks for the MAM lists
-    if (status != 0)
+    drain.dismiss();
+    if (ni == 0) { m.ran = true; return ULTRA_OK; }
+    const int64_t *h_close = m.pinned_base + (size_t)ni + 1;
+    m.total_mam = h_close[1];
+    m.nmam_on_host = m.exact_needed; // otherwise the counts are copied when a fetch asks for the MAM lists
+    if ((int32_t)h_close[2] != 0)
         return ultra_fail(ctx, ULTRA_E_ARG, "ultra_mam_run: an instance reached the reference's 'BUG' state in the n log n chainer");
-    m.total_chain = h_total;
+    m.total_chain = h_close[0];
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&m.ms[0], m.ev[0], m.ev[1]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&m.ms[1], m.ev[2], m.ev[3]));
     ULTRA_HIP_CHECK(ctx, hipEventElapsedTime(&m.ms[2], m.ev[3], m.ev[4]));
-    drain.dismiss();
     m.ran = true;
     return ULTRA_OK;
+}
+
+} // namespace
+
+// A run in two halves.  ultra_mam_run_begin returns when the whole run has been ENQUEUED (the host has the forward pass's
+// counts by then; the start pass, the traceback, the MAM build and the chainers are still in flight): the caller's thread
+// is free for the next batch, e.g. ultra_mam_plan_resident_behind on another context.  ultra_mam_run_end waits for the
+// device and closes the run; nothing of the results may be touched in between.
+extern "C" int ultra_mam_run_begin(ultra_ctx *ctx, double min_acc)
+{
+    if (!ctx) return ULTRA_E_ARG;
+    MamState &m = ctx->mam;
+    if (!m.staged || !ctx->my.staged) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_run: no staged batch");
+    if (m.begun) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_run_begin: the previous run has not been closed (ultra_mam_run_end)");
+    tail_state(ctx, true, false, false);
+    const int rc = mam_run_enqueue(ctx, min_acc);
+    if (rc != ULTRA_OK) { tail_state(ctx, false, false, false); return rc; }
+    {
+        // a run without a start pass (no pairs) never opened its tail: nobody must wait for it
+        std::lock_guard<std::mutex> lk(ctx->tail_mu);
+        ctx->tail_open = true;
+    }
+    ctx->tail_cv.notify_all();
+    m.begun = true;
+    return ULTRA_OK;
+}
+
+extern "C" int ultra_mam_run_end(ultra_ctx *ctx)
+{
+    if (!ctx) return ULTRA_E_ARG;
+    MamState &m = ctx->mam;
+    if (!m.begun) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_run_end: no run in flight (ultra_mam_run_begin)");
+    m.begun = false;
+    const int rc = mam_run_finish(ctx);
+    tail_state(ctx, false, false, false);
+    return rc;
+}
+
+extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
+{
+    const int rc = ultra_mam_run_begin(ctx, min_acc);
+    if (rc != ULTRA_OK) return rc;
+    return ultra_mam_run_end(ctx);
 }
 
 extern "C" int ultra_mam_sizes(const ultra_ctx *ctx, int64_t *n_chain_total, int64_t *n_mam_total)

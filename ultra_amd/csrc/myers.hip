@@ -2771,6 +2771,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[2], s));
+    {   // from here on the run is latency-bound: another context's planner may queue up behind this event
+        std::lock_guard<std::mutex> lk(ctx->tail_mu);
+        if (ctx->run_active) { ctx->tail_open = true; ctx->tail_has_event = true; }
+    }
+    ctx->tail_cv.notify_all();
     // The caller's mid-run work on a lane beside the traceback's routing (two chains of small kernels, the chip is
     // otherwise idle): the main stream takes it back in before the routing's copy to the host.
     bool hook_beside = false;

@@ -104,6 +104,9 @@ void slot_main(ultra_pipe *p, int si)
             if (p->stop && sl.state != 1) return;
         }
         const double t0 = now_ms();
+        // (Measured in round 3: ordering the planner's kernels behind the running slot's start pass -
+        // ultra_mam_plan_resident_behind - changes nothing here: 9.5 against 9.7 M reads/s.  The run's tail is short of
+        // wavefront slots too, the planner takes 8 ms beside it instead of 4.)
         int rc = ultra_mam_stage_nams(sl.ctx, p->dix, &sl.rq);
         if (rc == ULTRA_E_UNSUPPORTED) {
             // an instance beyond the device planner's envelope (or a 17th symbol): plan this batch on the host

@@ -22,11 +22,11 @@ EXPORTS = [
     "ultra_device_info", "ultra_host_alloc", "ultra_host_free", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
     "ultra_myers_last_timing", "ultra_myers_cell_counts", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
     "ultra_chain_mams_batch_noalloc", "ultra_chain_noalloc_capacity",
-    "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
+    "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_run_begin", "ultra_mam_run_end", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
     "ultra_index_create", "ultra_index_destroy", "ultra_plan_create", "ultra_plan_input", "ultra_plan_cands",
     "ultra_plan_destroy", "ultra_plan_last_error", "ultra_pyset_order",
     "ultra_dindex_create", "ultra_dindex_destroy", "ultra_dindex_last_error", "ultra_mam_stage_nams", "ultra_mam_upload_nams",
-    "ultra_mam_plan_resident", "ultra_mam_counts",
+    "ultra_mam_plan_resident", "ultra_mam_plan_resident_behind", "ultra_mam_counts",
     "ultra_mam_fetch_plan",
     "ultra_pipe_create", "ultra_pipe_destroy", "ultra_pipe_last_error", "ultra_pipe_submit", "ultra_pipe_pending",
     "ultra_pipe_wait", "ultra_pipe_release", "ultra_pipe_timing", "ultra_sg_affine_batch",
@@ -149,6 +149,8 @@ def load():
     lib.ultra_mam_batch.argtypes = [vp, C.POINTER(MamInput), C.c_double, C.POINTER(MamOutput)]
     lib.ultra_mam_stage.argtypes = [vp, C.POINTER(MamInput)]
     lib.ultra_mam_run.argtypes = [vp, C.c_double]
+    lib.ultra_mam_run_begin.argtypes = [vp, C.c_double]
+    lib.ultra_mam_run_end.argtypes = [vp]
     lib.ultra_mam_sizes.argtypes = [vp, i64p, i64p]
     lib.ultra_mam_fetch.argtypes = [vp, C.POINTER(MamOutput)]
     lib.ultra_mam_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
@@ -172,6 +174,7 @@ def load():
     lib.ultra_mam_stage_nams.argtypes = [vp, vp, C.POINTER(PlanRequest)]
     lib.ultra_mam_upload_nams.argtypes = [vp, C.POINTER(PlanRequest)]
     lib.ultra_mam_plan_resident.argtypes = [vp, vp]
+    lib.ultra_mam_plan_resident_behind.argtypes = [vp, vp, vp]
     lib.ultra_mam_counts.argtypes = [vp, i32p, i32p, i32p]
     lib.ultra_mam_fetch_plan.argtypes = [vp, i64p, i32p, i64p, i64p, u8p, i32p, i32p, i32p, i32p, i32p, i32p, i32p,
                                          i64p, i32p, i64p, i32p, i32p]
@@ -395,6 +398,11 @@ class Context(object):
     def mam_plan_resident(self, dindex):
         """Plans and stages the uploaded request again, from HBM (ultra_mam_plan_resident)."""
         self._check(self.lib.ultra_mam_plan_resident(self._h, dindex.handle))
+
+    def mam_plan_resident_behind(self, dindex, front):
+        """mam_plan_resident with the planner's kernels behind the start pass of the run `front` (another Context of this
+        GPU) has in flight (ultra_mam_plan_resident_behind)."""
+        self._check(self.lib.ultra_mam_plan_resident_behind(self._h, dindex.handle, front._h if front is not None else None))
         self._staged_n = self.mam_counts()[2]
 
     def mam_counts(self):
@@ -429,6 +437,13 @@ class Context(object):
 
     def mam_run(self, min_acc):
         self._check(self.lib.ultra_mam_run(self._h, float(min_acc)))
+
+    def mam_run_begin(self, min_acc):
+        """Enqueues the whole run and returns with its tail in flight (ultra_mam_run_begin); mam_run_end() closes it."""
+        self._check(self.lib.ultra_mam_run_begin(self._h, float(min_acc)))
+
+    def mam_run_end(self):
+        self._check(self.lib.ultra_mam_run_end(self._h))
 
     def mam_timing(self):
         ms = (C.c_float * 3)()
