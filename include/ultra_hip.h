@@ -65,6 +65,12 @@ int ultra_device_info(const ultra_ctx *ctx, char *name, int name_cap, int *n_cu,
  * link's rate and beside the caller's thread when they start in page-locked memory.  No reference counterpart. */
 int ultra_host_alloc(size_t bytes, void **out);
 void ultra_host_free(void *p);
+/* Debug canaries (no reference counterpart; SURVEY.md section 5 asks for them because ROCm has no compute-sanitizer): with
+ * ULTRA_CANARIES=1 in the environment when the library is loaded, every device buffer is allocated at exactly the size
+ * asked for between two 256-byte guard regions.  This call synchronises and reads every live buffer's guards back:
+ * *n_damaged > 0 means a kernel stored out of bounds.  self_test != 0 also overruns a scratch buffer by one byte and
+ * requires the check to notice.  ULTRA_E_STATE when the mode is off.  tests/test_gpu_canaries.py runs the hot path under it. */
+int ultra_debug_canaries(int64_t *n_buffers, int64_t *n_damaged, int self_test);
 
 /*
  * Batched semi-global ("HW", infix) Myers bit-vector search with locations and first-location path

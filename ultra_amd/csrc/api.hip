@@ -2,9 +2,80 @@
 #include "common.h"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
+// ---- debug canaries (common.h) ----
+namespace {
+std::mutex g_canary_mu;
+std::map<void *, std::pair<size_t, int>> g_canaries; // hipMalloc base -> (payload bytes, device)
+}
+
+bool ultra_canaries_on()
+{
+    static const bool on = [] { const char *e = getenv("ULTRA_CANARIES"); return e && *e && strcmp(e, "0") != 0; }();
+    return on;
+}
+
+void ultra_canary_note(void *base, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    g_canaries[base] = {bytes, dev};
+}
+
+void ultra_canary_drop(void *base)
+{
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    g_canaries.erase(base);
+}
+
 extern "C" {
+
+// Reads back the guard regions of every live device buffer of the process (all contexts, indexes, pipes).  Synchronises
+// the devices first.  self_test != 0: additionally allocates a buffer, overruns it by one byte on purpose and requires the
+// check to see it (answers ULTRA_E_STATE when it does not).
+int ultra_debug_canaries(int64_t *n_buffers, int64_t *n_damaged, int self_test)
+{
+    if (n_buffers) *n_buffers = 0;
+    if (n_damaged) *n_damaged = 0;
+    if (!ultra_canaries_on()) return ULTRA_E_STATE;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    auto damaged = [](void *base, size_t bytes) -> int {
+        uint8_t g[2 * kCanaryBytes];
+        if (hipMemcpy(g, base, kCanaryBytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (hipMemcpy(g + kCanaryBytes, (char *)base + kCanaryBytes + bytes, kCanaryBytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        for (size_t i = 0; i < 2 * kCanaryBytes; i++) if (g[i] != 0xA5) return 1;
+        return 0;
+    };
+    int rc = ULTRA_OK;
+    if (self_test) {
+        DevBuf t;
+        if (t.ensure(1000) != hipSuccess) return ULTRA_E_HIP;
+        const bool clean = damaged(t.base, 1000) == 0;
+        (void)hipMemset(t.p, 0, 1001); // one byte too many
+        const bool seen = damaged(t.base, 1000) == 1;
+        t.release();
+        if (!clean || !seen) return ULTRA_E_STATE;
+    }
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    int64_t nb = 0, nd = 0;
+    for (auto &kv : g_canaries) {
+        if (hipSetDevice(kv.second.second) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = ULTRA_E_HIP; break; }
+        const int d = damaged(kv.first, kv.second.first);
+        if (d < 0) { rc = ULTRA_E_HIP; break; }
+        nb++;
+        if (d) { nd++; fprintf(stderr, "ultra_debug_canaries: guard of a %zu-byte device buffer damaged\n", kv.second.first); }
+    }
+    (void)hipSetDevice(cur);
+    if (n_buffers) *n_buffers = nb;
+    if (n_damaged) *n_damaged = nd;
+    return rc;
+}
 
 void ultra_cfg_default(ultra_cfg *cfg)
 {

@@ -11,23 +11,48 @@
 
 #include "../../include/ultra_hip.h"
 
+// Debug canaries (there is no compute-sanitizer on ROCm): with ULTRA_CANARIES=1 in the environment
+// every device buffer of the library is allocated at exactly the size asked for, between two guard regions of
+// kCanaryBytes filled with a pattern; ultra_debug_canaries() reads the guards of every live buffer back.  An
+// out-of-bounds store of a kernel then shows up as a damaged guard instead of a corrupted neighbour (csrc/api.hip).
+constexpr size_t kCanaryBytes = 256;
+bool ultra_canaries_on();
+void ultra_canary_note(void *base, size_t bytes);
+void ultra_canary_drop(void *base);
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    void *base = nullptr; // what hipMalloc returned (= p unless the buffer sits between canaries)
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        release();
+        if (ultra_canaries_on()) {
+            hipError_t e = hipMalloc(&base, bytes + 2 * kCanaryBytes);
+            if (e != hipSuccess) { base = nullptr; return e; }
+            e = hipMemset(base, 0xA5, kCanaryBytes);
+            if (e == hipSuccess) e = hipMemset((char *)base + kCanaryBytes + bytes, 0xA5, kCanaryBytes);
+            if (e != hipSuccess) { (void)hipFree(base); base = nullptr; return e; }
+            p = (char *)base + kCanaryBytes;
+            cap = bytes;
+            ultra_canary_note(base, bytes);
+            return hipSuccess;
+        }
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return e; }
+        base = p;
         cap = want;
         return hipSuccess;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        if (base) {
+            if (base != p) ultra_canary_drop(base);
+            (void)hipFree(base);
+        }
+        p = base = nullptr; cap = 0;
     }
     template <typename T> T *as() const { return (T *)p; }
 };

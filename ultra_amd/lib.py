@@ -19,7 +19,7 @@ _ERR_NAMES = {-1: "ULTRA_E_ARG", -2: "ULTRA_E_HIP", -3: "ULTRA_E_CAPACITY", -4: 
 
 EXPORTS = [
     "ultra_cfg_default", "ultra_ctx_create", "ultra_ctx_destroy", "ultra_last_error", "ultra_device_count",
-    "ultra_device_info", "ultra_host_alloc", "ultra_host_free", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
+    "ultra_device_info", "ultra_host_alloc", "ultra_host_free", "ultra_debug_canaries", "ultra_myers_hw_batch", "ultra_myers_stage", "ultra_myers_run", "ultra_myers_fetch",
     "ultra_myers_last_timing", "ultra_myers_cell_counts", "ultra_myers_class_timing", "ultra_chain_mams_batch", "ultra_chain_nams_batch",
     "ultra_chain_mams_batch_noalloc", "ultra_chain_noalloc_capacity",
     "ultra_mam_batch", "ultra_mam_stage", "ultra_mam_run", "ultra_mam_run_begin", "ultra_mam_run_end", "ultra_mam_sizes", "ultra_mam_fetch", "ultra_mam_last_timing",
@@ -132,6 +132,7 @@ def load():
     lib.ultra_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     lib.ultra_host_free.argtypes = [vp]
     lib.ultra_host_free.restype = None
+    lib.ultra_debug_canaries.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]
     lib.ultra_myers_hw_batch.argtypes = [vp, u8p, C.c_size_t, C.c_int32, i64p, i32p, i64p, i32p, i32p,
                                          i32p, i32p, i64p, i32p, i32p, C.c_int64, i64p, i32p, u8p, i64p, i32p]
     lib.ultra_myers_stage.argtypes = [vp, u8p, C.c_size_t, C.c_int32, i64p, i32p, i64p, i32p, i32p]
