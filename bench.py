@@ -81,6 +81,7 @@ def parse_args():
                     help="timed region: 1 = one host thread, the planner of batch i + 1 behind the start pass of batch i's run (ultra_mam_run_begin / "
                          "_plan_resident_behind / _run_end; measured 1.5 %% faster, but the planner then runs inside the tail's stage timers); "
                          "0 = plan and run strictly one after the other, and the pipelined loop is an extra leg behind the timed region")
+    ap.add_argument("--pipe-leg", type=int, default=1, help="the pipelined loop as an extra leg behind the timed region (0 = skip; the profile scripts do)")
     ap.add_argument("--front-rounds", type=int, default=2, help="passes over two batches through the native front end (0 = skip)")
     ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
     ap.add_argument("--micro-scale", type=float, default=1.0, help="fraction of the micro-benchmarks' pair counts")
@@ -348,7 +349,7 @@ def main():
     pipe_leg = None
     if not pipelined:
         seq_acc, seq_tot, n_seq, seq_elapsed = acc, tot, args.steps, elapsed
-        if n_thr == 1 and nb >= 2 and world == 1:
+        if n_thr == 1 and nb >= 2 and world == 1 and args.pipe_leg:
             # the pipelined loop as an extra leg (not `value`): its planner runs inside the tail's stage timers
             _, p_acc, p_tot = new_acc()
             torch.cuda.synchronize()

@@ -10,8 +10,8 @@ q=${ULTRA_HW_QUEUES:-16}; [ "$q" -ge 1 ] 2>/dev/null || q=16; [ "$q" -gt 32 ] &&
 export TMPDIR=/tmp GPU_MAX_HW_QUEUES=$q ULTRA_HW_QUEUES=$q
 out=gpurun_out/prof_$tag
 mkdir -p $out
-B="python3 bench.py --steps 10 --warmup 2 --cpu-seconds 0 --check 0 --e2e-rounds 0 --front-rounds 0 --micro 0"
-S="python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --check 0 --e2e-rounds 0 --front-rounds 0 --micro 0"
+B="python3 bench.py --steps 10 --warmup 2 --cpu-seconds 0 --check 0 --e2e-rounds 0 --front-rounds 0 --micro 0 --pipe-leg 0"
+S="python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --check 0 --e2e-rounds 0 --front-rounds 0 --micro 0 --pipe-leg 0"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- $B > $out/kt.log 2>&1 || exit 1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o f --output-format csv -- $S > $out/fetch.log 2>&1 || exit 1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $out/write -o w --output-format csv -- $S > $out/write.log 2>&1 || exit 1
