@@ -86,6 +86,10 @@ struct MyersBucket {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+// A pair as the device planner writes it (one 32-byte record: the gather into sorted order then costs one random access
+// per pair instead of five).  The host entry points upload five arrays (u_qoff ...) instead: MyersState::u_packed tells.
+struct PairRec { int64_t q_off, t_off; int32_t q_len, t_len, k, pad; };
+
 struct MyersState {
     bool staged = false, ran = false;
     int32_t n_pairs = 0;
@@ -105,6 +109,8 @@ struct MyersState {
         locend, locstart, locpair, hitpairs, firstins, nops, trace, bounds, ops, opsoff, bandcls, banditems, bandinfo, sorttmp, trace2, startitems, startinfo, hbuf;
     // staging: raw bytes, byte -> code table (+ presence mask), the pairs as the caller ordered them, sort scratch,
     // sorted position -> caller's index and its inverse, per-class statistics, unsorted work items
+    bool u_packed = false;
+    DevBuf u_rec;
     DevBuf raw, lut, u_qoff, u_qlen, u_toff, u_tlen, u_k, skeys, perm_d, inv_d, stats, worktmp;
     // resident-pool mode (ultra_mam_stage_nams): arena = [pad | index pool | reads of the batch (reads_cap) | pad]; the pool
     // part is encoded once per (context, device index); byte -> code assignments only ever grow

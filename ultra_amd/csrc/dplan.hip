@@ -66,8 +66,7 @@ struct PlanArgs {
     const int64_t *cand_off, *pair_off;
     uint8_t *kind;
     int32_t *e_start, *e_stop, *pair, *pairc, *seq_len, *seq_id, *chr;
-    int64_t *q_off, *t_off;
-    int32_t *q_len, *t_len, *k;
+    PairRec *rec;        // the pairs, unsorted (MyersState::u_rec)
     int32_t *read_len;
     int64_t *fps, *lps;
     // what the count pass found out about an instance, kept for the fill pass (which then starts at the candidate list
@@ -560,12 +559,12 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
                 if (hp) {
                     pr = w++;
                     const int64_t g = pbase + pr;
-                    a.q_off[g] = v.off; a.q_len[g] = (int32_t)ls; a.t_off[g] = read_at; a.t_len[g] = (int32_t)lr; a.k[g] = width >= 9 ? kk : 0;
+                    a.rec[g] = PairRec{v.off, read_at, (int32_t)ls, (int32_t)lr, width >= 9 ? kk : 0, 0};
                 }
                 if (hpc) {
                     prc = w++;
                     const int64_t g = pbase + prc;
-                    a.q_off[g] = read_at; a.q_len[g] = (int32_t)lr; a.t_off[g] = v.off; a.t_len[g] = (int32_t)ls; a.k[g] = kk;
+                    a.rec[g] = PairRec{read_at, v.off, (int32_t)lr, (int32_t)ls, kk, 0};
                 }
             }
             // equal sequences share an id within the partial-segment loop and within the partial-flank loop (:479-523)
@@ -934,12 +933,11 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     ULTRA_HIP_CHECK(ctx, m.instbase.ensure((NI + 1) * 8)); ULTRA_HIP_CHECK(ctx, m.nmam.ensure(NI * 4));
     ULTRA_HIP_CHECK(ctx, m.chainlen.ensure(NI * 4 + 16)); ULTRA_HIP_CHECK(ctx, m.value.ensure(NI * 8));
     ULTRA_HIP_CHECK(ctx, m.lenw.ensure((NI + 1) * 8)); ULTRA_HIP_CHECK(ctx, m.chainoff.ensure((NI + 1) * 8));
-    ULTRA_HIP_CHECK(ctx, st.u_qoff.ensure(NP * 8)); ULTRA_HIP_CHECK(ctx, st.u_toff.ensure(NP * 8));
-    ULTRA_HIP_CHECK(ctx, st.u_qlen.ensure(NP * 4)); ULTRA_HIP_CHECK(ctx, st.u_tlen.ensure(NP * 4)); ULTRA_HIP_CHECK(ctx, st.u_k.ensure(NP * 4));
+    ULTRA_HIP_CHECK(ctx, st.u_rec.ensure(NP * sizeof(PairRec)));
     a.cand_off = m.candoff.as<int64_t>(); a.pair_off = m.p_poff.as<int64_t>();
     a.kind = m.kind.as<uint8_t>(); a.e_start = m.estart.as<int32_t>(); a.e_stop = m.estop.as<int32_t>(); a.pair = m.pair.as<int32_t>();
     a.pairc = m.pairc.as<int32_t>(); a.seq_len = m.seqlen.as<int32_t>(); a.seq_id = m.seqid.as<int32_t>(); a.chr = m.chr.as<int32_t>();
-    a.q_off = st.u_qoff.as<int64_t>(); a.t_off = st.u_toff.as<int64_t>(); a.q_len = st.u_qlen.as<int32_t>(); a.t_len = st.u_tlen.as<int32_t>(); a.k = st.u_k.as<int32_t>();
+    a.rec = st.u_rec.as<PairRec>();
     a.read_len = m.readlen.as<int32_t>(); a.fps = m.fps.as<int64_t>(); a.lps = m.lps.as<int64_t>();
     hipLaunchKernelGGL((k_plan<CAP_S, true>), dim3((unsigned)ni), dim3(64), plan_lds_bytes<CAP_S>(), s, a);
     if (n_over > 0) {
@@ -957,6 +955,7 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     if ((size_t)max_c * 28 > (size_t)160 * 1024 - 64)
         return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_mam_stage_nams: more than 5849 candidates in one instance");
     for (auto &e : m.ev) if (!e) ULTRA_HIP_CHECK(ctx, hipEventCreate(&e));
+    st.u_packed = true;
     int rc = ultra_myers_stage_pairs(ctx, (int32_t)npairs);
     if (rc != ULTRA_OK) return rc;
     if (nc > 0) {

@@ -2090,7 +2090,7 @@ void ultra_myers_free(ultra_ctx *ctx)
                       &st.packed, &st.scanned, &st.blocksum, &st.locoff, &st.hitoff, &st.locend, &st.locstart,
                       &st.locpair, &st.hitpairs, &st.firstins, &st.nops, &st.trace, &st.bounds, &st.ops, &st.opsoff,
                       &st.bandcls, &st.banditems, &st.bandinfo, &st.sorttmp, &st.trace2, &st.startitems, &st.startinfo,
-                      &st.hbuf, &st.raw, &st.lut, &st.u_qoff, &st.u_qlen, &st.u_toff, &st.u_tlen, &st.u_k, &st.skeys, &st.perm_d, &st.inv_d, &st.stats, &st.worktmp};
+                      &st.hbuf, &st.raw, &st.lut, &st.u_qoff, &st.u_qlen, &st.u_toff, &st.u_tlen, &st.u_k, &st.u_rec, &st.skeys, &st.perm_d, &st.inv_d, &st.stats, &st.worktmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : st.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (st.h_route) { (void)hipHostFree(st.h_route); st.h_route = nullptr; }
@@ -2182,7 +2182,8 @@ __device__ __forceinline__ bool pair_cannot_hit(int m, int t, int k)
 // stats, kStatN = 16 entries each: pairs per size class ([15] = skipped), forward cells per class ([15] = the cells the
 // skipped pairs would have cost), longest target per class, longest query per class
 constexpr int kStatN = 16;
-__global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const int32_t *t_len, const int32_t *k, int32_t n, uint32_t *keys,
+template <bool PACKED>
+__global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const int32_t *t_len, const int32_t *k, const PairRec *rec, int32_t n, uint32_t *keys,
                                                    int32_t *idx, unsigned long long *stats)
 {
     // 16 copies of the counters, a thread uses copy (thread & 15): the pairs of a wavefront mostly fall into two or three
@@ -2194,8 +2195,10 @@ __global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const i
     unsigned long long *sh = shc[threadIdx.x & (kCopies - 1)];
     // a few thousand blocks, each over many pairs: every block ends with up to 64 atomics on the same global counters
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-        const int m = q_len[p], t = t_len[p];
-        const uint32_t c = pair_cannot_hit(m, t, k[p]) ? kSkipClass : size_class_of(m);
+        int m, t, kp;
+        if (PACKED) { const PairRec r = rec[p]; m = r.q_len; t = r.t_len; kp = r.k; }
+        else { m = q_len[p]; t = t_len[p]; kp = k[p]; }
+        const uint32_t c = pair_cannot_hit(m, t, kp) ? kSkipClass : size_class_of(m);
         // Lane classes (m <= 256): queries that leave the lower half of their first word empty sort together, so that
         // whole wavefronts can run that word on one 32-bit half (lane_forward).
         const uint32_t half = (c < 4 && ((c + 1) * 64 - (uint32_t)m) >= 32) ? 1u : 0u;
@@ -2215,22 +2218,30 @@ __global__ void __launch_bounds__(256) k_pair_keys(const int32_t *q_len, const i
     }
 }
 
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_gather_pairs(const int32_t *perm, int32_t n, int64_t shift,
                                                       const int64_t *uq, const int32_t *uql, const int64_t *ut, const int32_t *utl, const int32_t *uk,
+                                                      const PairRec *rec,
                                                       int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len, int32_t *k, int32_t *inv,
                                                       int32_t *ed, int32_t *nloc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = perm[i];
-    q_off[i] = uq[p] + shift; t_off[i] = ut[p] + shift;
-    q_len[i] = uql[p]; t_len[i] = utl[p]; k[i] = uk[p];
+    PairRec r;
+    if (PACKED) r = rec[p]; // one 32-byte access instead of five lines
+    else { r.q_off = uq[p]; r.t_off = ut[p]; r.q_len = uql[p]; r.t_len = utl[p]; r.k = uk[p]; }
+    q_off[i] = r.q_off + shift; t_off[i] = r.t_off + shift;
+    q_len[i] = r.q_len; t_len[i] = r.t_len; k[i] = r.k;
     inv[p] = i;
     // the pairs no launch takes (pair_cannot_hit) are answered here; every run of the staged batch leaves them alone
-    if (pair_cannot_hit(uql[p], utl[p], uk[p])) { ed[i] = -1; nloc[i] = 0; }
+    if (pair_cannot_hit(r.q_len, r.t_len, r.k)) { ed[i] = -1; nloc[i] = 0; }
 }
 
-struct WorkRanges { int32_t n; struct { int32_t cls, G, W, first_item; int64_t pb, pe; } r[5]; };
+// The forward work lists of all register buckets in one go: one launch makes the items, ONE sort orders them by
+// (bucket, cost descending), one launch deals them into the buckets' lists (five rounds of ~12 tiny launches before).
+struct WorkRanges { int32_t n; struct { int32_t cls, G, W, first_item, bucket; int64_t pb, pe; } r[kNumSizeClasses + 1]; };
+constexpr uint32_t kWorkCostMask = 0x0FFFFFFFu; // sort key = bucket << 28 | (mask - min(cost, mask))
 __global__ void __launch_bounds__(256) k_work_items(WorkRanges wr, const int32_t *q_len, const int32_t *t_len, int32_t n_items, WorkItem *items, uint32_t *keys, int32_t *idx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2247,13 +2258,18 @@ __global__ void __launch_bounds__(256) k_work_items(WorkRanges wr, const int32_t
     if (wr.r[r].cls == kLongClass) cost *= (q_len[last] + kStripRows - 1) / kStripRows; // one pair per item, strip after strip
     wi.cost = (int32_t)(cost < 0x7fffffff ? cost : 0x7fffffff);
     items[i] = wi;
-    keys[i] = (uint32_t)wi.cost;
+    const uint32_t c28 = (uint32_t)(cost < (int64_t)kWorkCostMask ? cost : (int64_t)kWorkCostMask);
+    keys[i] = ((uint32_t)wr.r[r].bucket << 28) | (kWorkCostMask - c28);
     idx[i] = i;
 }
-__global__ void __launch_bounds__(256) k_gather_work(const WorkItem *items, const int32_t *order, int32_t n, WorkItem *out)
+struct WorkOut { WorkItem *out[kBuckets]; int32_t first[kBuckets + 1]; };
+__global__ void __launch_bounds__(256) k_gather_work(const WorkItem *items, const int32_t *order, int32_t n, WorkOut wo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = items[order[i]];
+    if (i >= n) return;
+    int b = 0;
+    while (b + 1 < kBuckets && i >= wo.first[b + 1]) b++;
+    wo.out[b][i - wo.first[b]] = items[order[i]];
 }
 
 } // namespace
@@ -2306,18 +2322,30 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
     int32_t *i_in = (int32_t *)(k_out + np), *i_out = i_in + np;
     const unsigned gp = (unsigned)((n_pairs + 255) / 256);
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.stats.p, 0, 4 * kStatN * 8, s));
-    hipLaunchKernelGGL(k_pair_keys, dim3(std::min(gp, 2048u)), dim3(256), 0, s, st.u_qlen.as<int32_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(), n_pairs,
-                       k_in, i_in, st.stats.as<unsigned long long>());
+    if (st.u_packed)
+        hipLaunchKernelGGL(k_pair_keys<true>, dim3(std::min(gp, 2048u)), dim3(256), 0, s, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                           st.u_rec.as<PairRec>(), n_pairs, k_in, i_in, st.stats.as<unsigned long long>());
+    else
+        hipLaunchKernelGGL(k_pair_keys<false>, dim3(std::min(gp, 2048u)), dim3(256), 0, s, st.u_qlen.as<int32_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(),
+                           (const PairRec *)nullptr, n_pairs, k_in, i_in, st.stats.as<unsigned long long>());
     {
         size_t tmp_bytes = 0;
         ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 29, s));
         ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
         ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, i_in, st.perm_d.as<int32_t>(), (size_t)n_pairs, 0, 29, s));
     }
-    hipLaunchKernelGGL(k_gather_pairs, dim3(gp), dim3(256), 0, s, st.perm_d.as<int32_t>(), n_pairs, (int64_t)kArenaPad,
-                       st.u_qoff.as<int64_t>(), st.u_qlen.as<int32_t>(), st.u_toff.as<int64_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(),
-                       st.qoff.as<int64_t>(), st.qlen.as<int32_t>(), st.toff.as<int64_t>(), st.tlen.as<int32_t>(), st.k.as<int32_t>(),
-                       st.inv_d.as<int32_t>(), st.ed.as<int32_t>(), st.nloc.as<int32_t>());
+    if (st.u_packed)
+        hipLaunchKernelGGL(k_gather_pairs<true>, dim3(gp), dim3(256), 0, s, st.perm_d.as<int32_t>(), n_pairs, (int64_t)kArenaPad,
+                           (const int64_t *)nullptr, (const int32_t *)nullptr, (const int64_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                           st.u_rec.as<PairRec>(),
+                           st.qoff.as<int64_t>(), st.qlen.as<int32_t>(), st.toff.as<int64_t>(), st.tlen.as<int32_t>(), st.k.as<int32_t>(),
+                           st.inv_d.as<int32_t>(), st.ed.as<int32_t>(), st.nloc.as<int32_t>());
+    else
+        hipLaunchKernelGGL(k_gather_pairs<false>, dim3(gp), dim3(256), 0, s, st.perm_d.as<int32_t>(), n_pairs, (int64_t)kArenaPad,
+                           st.u_qoff.as<int64_t>(), st.u_qlen.as<int32_t>(), st.u_toff.as<int64_t>(), st.u_tlen.as<int32_t>(), st.u_k.as<int32_t>(),
+                           (const PairRec *)nullptr,
+                           st.qoff.as<int64_t>(), st.qlen.as<int32_t>(), st.toff.as<int64_t>(), st.tlen.as<int32_t>(), st.k.as<int32_t>(),
+                           st.inv_d.as<int32_t>(), st.ed.as<int32_t>(), st.nloc.as<int32_t>());
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     unsigned long long h_stats[4 * kStatN];
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_stats, st.stats.p, sizeof h_stats, hipMemcpyDeviceToHost, s));
@@ -2341,32 +2369,40 @@ int ultra_myers_stage_pairs(ultra_ctx *ctx, int32_t n_pairs)
     st.n_run = (int32_t)at; // the skipped pairs lie behind every class
     if (at + st.n_skipped != n_pairs) return ultra_fail(ctx, ULTRA_E_HIP, "ultra_myers_stage: size-class counts do not add up");
     // forward work lists (heaviest wavefront first), one per register bucket
-    for (int b = 0; b < kBuckets; b++) {
-        MyersBucket &bk = st.buckets[b];
+    {
         WorkRanges wr; wr.n = 0;
+        WorkOut wo;
         int32_t n_items = 0;
-        for (auto &mc : st.classes) {
-            const int cls = mc.cls;
-            if (bucket_of(cls) != b) continue;
-            const int per = 64 / mc.G;
-            wr.r[wr.n].cls = cls; wr.r[wr.n].G = mc.G; wr.r[wr.n].W = mc.W; wr.r[wr.n].first_item = n_items;
-            wr.r[wr.n].pb = mc.pb; wr.r[wr.n].pe = mc.pe;
-            wr.n++;
-            n_items += (int32_t)((mc.pe - mc.pb + per - 1) / per);
+        for (int b = 0; b < kBuckets; b++) {
+            MyersBucket &bk = st.buckets[b];
+            wo.first[b] = n_items;
+            for (auto &mc : st.classes) {
+                const int cls = mc.cls;
+                if (bucket_of(cls) != b) continue;
+                const int per = 64 / mc.G;
+                wr.r[wr.n].cls = cls; wr.r[wr.n].G = mc.G; wr.r[wr.n].W = mc.W; wr.r[wr.n].first_item = n_items; wr.r[wr.n].bucket = b;
+                wr.r[wr.n].pb = mc.pb; wr.r[wr.n].pe = mc.pe;
+                wr.n++;
+                n_items += (int32_t)((mc.pe - mc.pb + per - 1) / per);
+            }
+            bk.n_fwd = n_items - wo.first[b];
+            ULTRA_HIP_CHECK(ctx, bk.fwd_list.ensure((size_t)std::max(bk.n_fwd, 1) * sizeof(WorkItem)));
+            ULTRA_HIP_CHECK(ctx, bk.fwd_flag.ensure((size_t)std::max(bk.n_fwd, 1) * sizeof(int32_t)));
+            wo.out[b] = bk.fwd_list.as<WorkItem>();
         }
-        bk.n_fwd = n_items;
-        if (n_items <= 0) continue;
-        ULTRA_HIP_CHECK(ctx, bk.fwd_list.ensure((size_t)n_items * sizeof(WorkItem)));
-        ULTRA_HIP_CHECK(ctx, bk.fwd_flag.ensure((size_t)n_items * sizeof(int32_t)));
-        ULTRA_HIP_CHECK(ctx, st.worktmp.ensure((size_t)n_items * sizeof(WorkItem)));
-        const unsigned gi = (unsigned)((n_items + 255) / 256);
-        hipLaunchKernelGGL(k_work_items, dim3(gi), dim3(256), 0, s, wr, st.qlen.as<int32_t>(), st.tlen.as<int32_t>(), n_items, st.worktmp.as<WorkItem>(), k_in, i_in);
-        size_t tmp_bytes = 0;
-        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)n_items, 0, 32, s));
-        ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
-        ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs_desc(st.sorttmp.p, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)n_items, 0, 32, s));
-        hipLaunchKernelGGL(k_gather_work, dim3(gi), dim3(256), 0, s, st.worktmp.as<WorkItem>(), i_out, n_items, bk.fwd_list.as<WorkItem>());
-        ULTRA_HIP_CHECK(ctx, hipGetLastError());
+        wo.first[kBuckets] = n_items;
+        if (n_items > 0) {
+            // (an item holds at least one pair, so the pair sort's key / index scratch is large enough)
+            ULTRA_HIP_CHECK(ctx, st.worktmp.ensure((size_t)n_items * sizeof(WorkItem)));
+            const unsigned gi = (unsigned)((n_items + 255) / 256);
+            hipLaunchKernelGGL(k_work_items, dim3(gi), dim3(256), 0, s, wr, st.qlen.as<int32_t>(), st.tlen.as<int32_t>(), n_items, st.worktmp.as<WorkItem>(), k_in, i_in);
+            size_t tmp_bytes = 0;
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)n_items, 0, 31, s));
+            ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
+            ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)n_items, 0, 31, s));
+            hipLaunchKernelGGL(k_gather_work, dim3(gi), dim3(256), 0, s, st.worktmp.as<WorkItem>(), i_out, n_items, wo);
+            ULTRA_HIP_CHECK(ctx, hipGetLastError());
+        }
     }
     ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
     drain.dismiss();
@@ -2453,6 +2489,7 @@ int ultra_myers_stage_impl(ultra_ctx *ctx, const uint8_t *arena, size_t arena_le
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.u_k.p, k, np * 4, hipMemcpyHostToDevice, s));
     }
     drain.dismiss();
+    st.u_packed = false;
     return ultra_myers_stage_pairs(ctx, n_pairs);
 }
 
