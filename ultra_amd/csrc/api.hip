@@ -127,7 +127,24 @@ int ultra_ctx_create(int device, const ultra_cfg *cfg, ultra_ctx **out)
     for (int i = 0; i < kAuxStreams && ok; i++)
         ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < kXtraStreams && ok; i++)
+        ok = hipStreamCreateWithFlags(&ctx->xtra[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->xtra_ev[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { ultra_ctx_destroy(ctx); return ULTRA_E_HIP; }
+    {
+        // HIP binds a stream to one of the process's hardware queues at the stream's first command (the least loaded
+        // queue then).  First commands in creation order, here, give the lanes of one context queues of their own; left
+        // to the first batch, the order depended on which launches that batch happened to have, and two lanes of a
+        // context could end up behind each other on one queue for the life of the context.
+        void *warm = nullptr;
+        ok = hipMalloc(&warm, 256) == hipSuccess;
+        if (ok) ok = hipMemsetAsync(warm, 0, 4, ctx->stream) == hipSuccess;
+        for (int i = 0; i < kAuxStreams && ok; i++) ok = hipMemsetAsync((char *)warm + 8 + 4 * i, 0, 4, ctx->aux[i]) == hipSuccess;
+        for (int i = 0; i < kXtraStreams && ok; i++) ok = hipMemsetAsync((char *)warm + 64 + 4 * i, 0, 4, ctx->xtra[i]) == hipSuccess;
+        if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+        if (warm) (void)hipFree(warm);
+        if (!ok) { ultra_ctx_destroy(ctx); return ULTRA_E_HIP; }
+    }
     if (ultra_chain_scratch_init(ctx) != ULTRA_OK) { ultra_ctx_destroy(ctx); return ULTRA_E_HIP; }
     *out = ctx;
     return ULTRA_OK;
@@ -145,6 +162,10 @@ void ultra_ctx_destroy(ultra_ctx *ctx)
     for (int i = 0; i < kAuxStreams; i++) {
         if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
         if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
+    }
+    for (int i = 0; i < kXtraStreams; i++) {
+        if (ctx->xtra[i]) { (void)hipStreamSynchronize(ctx->xtra[i]); (void)hipStreamDestroy(ctx->xtra[i]); }
+        if (ctx->xtra_ev[i]) (void)hipEventDestroy(ctx->xtra_ev[i]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

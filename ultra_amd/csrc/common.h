@@ -164,6 +164,7 @@ struct AffineState {
 // hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise before the first HIP call) share a
 // queue and serialise, so the default lane count follows that variable (ultra_ctx_create).
 constexpr int kAuxStreams = 7;
+constexpr int kXtraStreams = 4;
 constexpr int kLanes = kAuxStreams + 1;
 
 // Distinct bytes of a batch (dense codes, byte-exact comparison).  The match table of a wavefront is S x words x 512 B of
@@ -178,6 +179,11 @@ struct ultra_ctx {
     // size classes of one pass are independent: they are launched round-robin on these streams so
     // that short launches overlap (fork = aux streams wait for `stream`, join = `stream` waits for them)
     hipStream_t aux[kAuxStreams] = {};
+    // Streams beyond the lanes, for the traceback's full-height launches (hits whose distance no band class takes: long
+    // reads against the reference's generous k): on a lane they stood in front of a band class's launch, which then
+    // started when they had ended (dRNA: 4.7 + 3.5 ms in a row, Iso-Seq 2.2 + 3.1).  Joined by ultra_join_xtra.
+    hipStream_t xtra[kXtraStreams] = {};
+    hipEvent_t xtra_ev[kXtraStreams] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kAuxStreams] = {};
     // lane i of a forked section: the auxiliary streams in use, then the main stream itself
     hipStream_t lane(int i) const { i %= cfg.launch_lanes; return i < cfg.launch_lanes - 1 ? aux[i] : stream; }
@@ -241,6 +247,7 @@ struct ultra_drain_guard {
     {
         if (!armed) return;
         for (int i = 0; i < kAuxStreams; i++) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
+        for (int i = 0; i < kXtraStreams; i++) if (ctx->xtra[i]) (void)hipStreamSynchronize(ctx->xtra[i]);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     }
 };

@@ -2834,6 +2834,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     for (auto &v : h_band) v = 0;
     a.nw_items = nullptr;
     bool forked = false;
+    int xtra_used = 0; // streams beyond the lanes that carry a full-height launch of this run
     bool hook_arrived = false; // a host synchronisation has followed the caller's mid-run work on s
     int32_t full_first[kNumSizeClasses + 1], full_edmax[kNumSizeClasses];
     for (auto &v : full_first) v = 0;
@@ -3019,9 +3020,17 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             b.begin = it->begin; b.end = it->end;
             b.nw_items = use_band ? d_items_sorted : nullptr;
             // a lane of their own while there are lanes; beyond that beside the 1-word band and up, never behind the
-            // 32-row band's launch (lane 0, the longest of the phase)
+            // 32-row band's launch (lane 0, the longest of the phase).  With the full set of lanes (16 hardware queues) and
+            // the band classes on them, they go to streams of their own instead.
             int li = kBandClasses + q;
             const int lanes = ctx->cfg.launch_lanes;
+            static const bool no_xtra = getenv("ULTRA_DEV_NO_XTRA") != nullptr;
+            if (use_band && lanes == kLanes && !no_xtra) {
+                const int xi = q % kXtraStreams;
+                if (!(xtra_used >> xi & 1)) { ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->xtra[xi], ctx->fork_ev, 0)); xtra_used |= 1 << xi; }
+                ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->xtra[xi], it->cls, b, it->items, it->max_par));
+                continue;
+            }
             if (li >= lanes && lanes > 1) li = 1 + (li - lanes) % (lanes - 1);
             ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->lane(li), it->cls, b, it->items, it->max_par));
         }
@@ -3031,6 +3040,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         if (rc != ULTRA_OK) return rc;
     }
     if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    for (int xi = 0; xi < kXtraStreams; xi++)
+        if (xtra_used >> xi & 1) {
+            ULTRA_HIP_CHECK(ctx, hipEventRecord(ctx->xtra_ev[xi], ctx->xtra[xi]));
+            ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->xtra_ev[xi], 0));
+        }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[3], s));
     if (hook_early) { // joined into s with the start pass; its copies have landed once its event has
         ULTRA_HIP_CHECK(ctx, hipEventSynchronize(st.ev[6]));
