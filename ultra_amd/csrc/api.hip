@@ -137,11 +137,14 @@ int ultra_ctx_create(int device, const ultra_cfg *cfg, ultra_ctx **out)
         // to the first batch, the order depended on which launches that batch happened to have, and two lanes of a
         // context could end up behind each other on one queue for the life of the context.
         void *warm = nullptr;
-        ok = hipMalloc(&warm, 256) == hipSuccess;
+        static const bool no_bind = getenv("ULTRA_DEV_NO_BIND") != nullptr;
+        ok = no_bind || hipMalloc(&warm, 256) == hipSuccess;
+        if (!no_bind) {
         if (ok) ok = hipMemsetAsync(warm, 0, 4, ctx->stream) == hipSuccess;
         for (int i = 0; i < kAuxStreams && ok; i++) ok = hipMemsetAsync((char *)warm + 8 + 4 * i, 0, 4, ctx->aux[i]) == hipSuccess;
         for (int i = 0; i < kXtraStreams && ok; i++) ok = hipMemsetAsync((char *)warm + 64 + 4 * i, 0, 4, ctx->xtra[i]) == hipSuccess;
         if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+        }
         if (warm) (void)hipFree(warm);
         if (!ok) { ultra_ctx_destroy(ctx); return ULTRA_E_HIP; }
     }

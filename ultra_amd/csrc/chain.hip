@@ -683,7 +683,7 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
     // the one stream it was given.
     const int n_launch = (n_tiny_launch > 0) + !small.empty() + !big.empty() + !tree.empty();
     const bool spread = !ws && ctx->cfg.launch_lanes > 1 && n_launch > 1;
-    if (spread) ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_fork_at(ctx, 6));
     int li = 0;
     auto next_lane = [&]() { return spread ? ctx->lane(li++) : s; };
     if (!tree.empty()) { // longest critical path first
@@ -722,7 +722,7 @@ int ultra_chain_launch(ultra_ctx *ctx, int32_t n_inst, const int32_t *h_cnt, con
         hipLaunchKernelGGL(chain_tiny, dim3((unsigned)((n_tiny_launch + 63) / 64)), dim3(64), 0, cs, a);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
-    if (spread) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_join_at(ctx, 7));
     return ULTRA_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -165,6 +166,9 @@ struct AffineState {
 // queue and serialise, so the default lane count follows that variable (ultra_ctx_create).
 constexpr int kAuxStreams = 7;
 constexpr int kXtraStreams = 4;
+#ifndef ULTRA_HOSTSYNC_DEFAULT
+#define ULTRA_HOSTSYNC_DEFAULT 0x14u
+#endif
 constexpr int kLanes = kAuxStreams + 1;
 
 // Distinct bytes of a batch (dense codes, byte-exact comparison).  The match table of a wavefront is S x words x 512 B of
@@ -232,6 +236,26 @@ static inline hipError_t ultra_join(ultra_ctx *ctx)
         e = hipEventRecord(ctx->join_ev[i], ctx->aux[i]);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->join_ev[i], 0);
     }
+    return e;
+}
+
+// Experiment knob (ULTRA_DEV_HOSTSYNC = bit mask of points): at a fork the host first waits for the main stream, at a join
+// the host waits for the lanes instead of the main stream waiting for their events on the device.
+static inline unsigned ultra_hostsync_mask()
+{
+    static const unsigned m = [] { const char *e = getenv("ULTRA_DEV_HOSTSYNC"); return e ? (unsigned)strtoul(e, nullptr, 0) : ULTRA_HOSTSYNC_DEFAULT; }();
+    return m;
+}
+static inline hipError_t ultra_fork_at(ultra_ctx *ctx, int point)
+{
+    if (ultra_hostsync_mask() >> point & 1u) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) return e; }
+    return ultra_fork(ctx);
+}
+static inline hipError_t ultra_join_at(ultra_ctx *ctx, int point)
+{
+    if (!(ultra_hostsync_mask() >> point & 1u)) return ultra_join(ctx);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < ctx->cfg.launch_lanes - 1 && e == hipSuccess; i++) e = hipStreamSynchronize(ctx->aux[i]);
     return e;
 }
 

@@ -2562,7 +2562,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bounds.as<int64_t>() + 120, 0, kBuckets * 4, s)); // lengths of the buckets' re-run lists
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[0], s));
     // ---- pass 1: forward HW ----
-    ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    ULTRA_HIP_CHECK(ctx, ultra_fork_at(ctx, 0));
     static const DevList dev_order = dev_list("ULTRA_DEV_FWD_ORDER"); // buckets in launch order
     for (int bi = 0; bi < kBuckets; bi++) {
         const int b = dev_order.n == kBuckets && dev_order.v[bi] < kBuckets ? dev_order.v[bi] : kBuckets - 1 - bi;
@@ -2596,7 +2596,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         } else ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD>(ctx, a, b, bk.fwd_list.as<WorkItem>(), bk.n_fwd, 0, 1, lane_b));
         ULTRA_HIP_CHECK(ctx, hipEventRecord(bk.ev1, cs));
     }
-    ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    ULTRA_HIP_CHECK(ctx, ultra_join_at(ctx, 1));
     ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[4], s)); // all forward launches done
     // The caller's mid-run work only needs the forward pass.  With eight lanes it goes onto the last auxiliary lane now,
     // beside the offsets below (a chain of small kernels on an otherwise idle chip); every later join takes it back in.
@@ -2709,7 +2709,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         // Full-height reverse pass: one launch per register bucket on the bucket's own lane.  A bucket's start pass
         // only reads end columns of the bucket's own pairs, so the re-run and the start pass follow each other in
         // the lane without a join in between: one bucket's re-run rides under the other buckets' start passes.
-        ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+        ULTRA_HIP_CHECK(ctx, ultra_fork_at(ctx, 2));
         for (int b = kBuckets - 1; b >= 0; b--) {
             if (h_overflow[b]) // only the buckets that have such a pair: an idle launch would still hold the bucket's lane
                 ULTRA_HIP_CHECK(ctx, launch_mega<MODE_FWD_EXACT>(ctx, a, b, st.buckets[b].fwd_list.as<WorkItem>(), h_rerun[b]));
@@ -2728,7 +2728,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             st.buckets[b].n_rev = blocks;
             ULTRA_HIP_CHECK(ctx, launch_mega<MODE_REV>(ctx, ab, b, nullptr, blocks));
         }
-        ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+        ULTRA_HIP_CHECK(ctx, ultra_join_at(ctx, 3));
     } else {
         // Banded reverse pass, lane per location.  The locations are sorted by (band class, columns) so that the
         // lanes of a wavefront run equally long; what no band class takes (distance > 59) goes through the
@@ -2858,6 +2858,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
             ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kTbKeyBits, s));
         }
+        if (ultra_hostsync_mask() >> 4 & 1u) ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         ULTRA_HIP_CHECK(ctx, hipEventSynchronize(st.ev[5])); // the counts: on the host since the start pass began
         {   // hits per group -> first sorted position of every group, then the end
             int32_t acc = 0;
@@ -3039,7 +3040,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         const int rc = launch_bands();
         if (rc != ULTRA_OK) return rc;
     }
-    if (forked) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    if (forked) ULTRA_HIP_CHECK(ctx, ultra_join_at(ctx, 5));
     for (int xi = 0; xi < kXtraStreams; xi++)
         if (xtra_used >> xi & 1) {
             ULTRA_HIP_CHECK(ctx, hipEventRecord(ctx->xtra_ev[xi], ctx->xtra[xi]));
