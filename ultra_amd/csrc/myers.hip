@@ -35,14 +35,17 @@ enum { kBandClasses = 8, kBandFallback = 8 }; // banded traceback: 32 rows, then
 // 24-word class over 8 lanes measured slower than those for the few hits beyond).
 __host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : 16; } // classes 1..7
 #ifndef ULTRA_BANDG_GEOM
-#define ULTRA_BANDG_GEOM 1
+#define ULTRA_BANDG_GEOM 2
 #endif
 #if ULTRA_BANDG_GEOM == 0
 __host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 2 : c == 4 ? 3 : c == 5 ? 4 : c == 6 ? 4 : 8; }    // lanes per hit
-#else
+#elif ULTRA_BANDG_GEOM == 1
 // one word per lane up to 8 words, two beyond: the wide bands are few, long wavefronts whose length is the length of the
 // traceback phase, and a column costs a lane about 30 instructions + 40 per word
 __host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 6 : 8; }    // lanes per hit
+#else
+// one word per lane throughout (12 lanes: five hits per wavefront; 16: four, a DPP row each)
+__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : 16; }    // lanes per hit
 #endif
 __host__ __device__ constexpr int band_rows(int c) { return c == 0 ? 32 : 64 * band_words(c); }
 #ifndef ULTRA_BAND_K0
@@ -1064,7 +1067,7 @@ __global__ void __launch_bounds__(64) myers_bandg(MyArgs a, const int32_t *items
         // value of lane + 1 as a DPP move (a VALU instruction, not a trip through the LDS crossbar): groups of 2, 4 and 8
         // lanes never straddle a row of 16, groups of 3 do
         auto from_next_lane = [&](int v) {
-            return (G == 3 || G == 6) ? __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
+            return (G == 3 || G == 6 || G == 12) ? __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
                           : __builtin_amdgcn_update_dpp(0, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
         };
         auto push_row = [&](uint32_t code1) { // the whole window moves down one row; the top lane takes the new row's code
