@@ -85,7 +85,7 @@ def parse_args():
     ap.add_argument("--front-rounds", type=int, default=2, help="passes over two batches through the native front end (0 = skip)")
     ap.add_argument("--micro", type=int, default=1, help="run the Myers micro-benchmarks (rank 0)")
     ap.add_argument("--micro-scale", type=float, default=1.0, help="fraction of the micro-benchmarks' pair counts")
-    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (default 16)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (default: ultra_amd.hwq.DEFAULT)")
     ap.add_argument("--lanes", type=int, default=0, help="launch lanes (HIP streams) per context, 0 = one per hardware queue")
     ap.add_argument("--slots", type=int, default=0, help="end positions kept per pair in the first pass, 0 = library default")
     ap.add_argument("--banded-starts", type=int, default=-1, help="start pass: 1 banded, 0 full height, -1 library default")

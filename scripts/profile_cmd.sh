@@ -3,7 +3,7 @@
 #   bash scripts/profile_cmd.sh <tag> scripts/dev/dev_probe.py 6000 262144
 set -o pipefail
 tag=${1:-q}; shift
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=16
+export TMPDIR=/tmp GPU_MAX_HW_QUEUES=13 ULTRA_HW_QUEUES=13
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 timeout -s KILL 280 rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 "$@" > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }

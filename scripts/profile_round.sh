@@ -2,11 +2,11 @@
 # One round's profile evidence, on the GPU box from the repo root:  bash scripts/profile_round.sh r01
 # Kernel times (--kernel-trace --stats), HBM traffic (separate --pmc passes, FETCH_SIZE / WRITE_SIZE) and the
 # SQ instruction/occupancy counters of the same bench command.  GPU_MAX_HW_QUEUES is exported here because the
-# profiler initialises HIP before bench.py could set it: 16 queues, bench.py's own default, clamped to the
+# profiler initialises HIP before bench.py could set it: 13 queues, bench.py's own default, clamped to the
 # pool's limit of 32 and exported under both names (ultra_amd/hwq.py: the bench line then records the count in force).
 set -o pipefail
 tag=${1:-r01}
-q=${ULTRA_HW_QUEUES:-16}; [ "$q" -ge 1 ] 2>/dev/null || q=16; [ "$q" -gt 32 ] && q=32
+q=${ULTRA_HW_QUEUES:-13}; [ "$q" -ge 1 ] 2>/dev/null || q=13; [ "$q" -gt 32 ] && q=32
 export TMPDIR=/tmp GPU_MAX_HW_QUEUES=$q ULTRA_HW_QUEUES=$q
 out=gpurun_out/prof_$tag
 mkdir -p $out

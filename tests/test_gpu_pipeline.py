@@ -280,7 +280,7 @@ def test_pc_main_runs_the_reference_protocol(ctx, tmp_path, per_gpu):
     args.outfolder, SAM rows appended to the output file, the 8-entry totals returned.  Same rows as align_single run
     in this process on the same records (base-level alignment on the GPU in both)."""
     from tests import helpers
-    from ultra_amd import align, indexer, pc, seed_wrapper, seeder
+    from ultra_amd import align, hwq, indexer, pc, seed_wrapper, seeder
     here = os.path.dirname(os.path.abspath(__file__))
     sirv = os.path.join(here, "golden", "sirv")
     out = str(tmp_path)
@@ -301,7 +301,7 @@ def test_pc_main_runs_the_reference_protocol(ctx, tmp_path, per_gpu):
     totals = pc.main(reads_path, seeds_path, sam_path, args)
     # the consumers are spawned children: they must run with the benched queue count, not HIP's default of 4
     for w in range(per_gpu):
-        assert "GPU_MAX_HW_QUEUES=16" in open(os.path.join(out, "uLTRA_batch_%d.stderr" % w)).read()
+        assert "GPU_MAX_HW_QUEUES=%d" % hwq.DEFAULT in open(os.path.join(out, "uLTRA_batch_%d.stderr" % w)).read()
     rows = open(sam_path).read().splitlines(True)
     # the same records through align_single in this process
     with open(reads_path) as fh:

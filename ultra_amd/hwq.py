@@ -9,10 +9,15 @@ import os
 
 HIP_DEFAULT = 4
 POOL_MAX = 32     # the GPU pool refuses more
-# Default 16: a context deals its launches over 8 lanes (streams), and the end-to-end pipeline keeps two contexts busy at
-# once - with 8 queues their 16 streams share queues pairwise, one context's staging kernels wait behind the other's
-# 12 ms forward launches and the pipeline delivers 6.9 - 7.9 M reads/s instead of 8.9 M.  The device-resident step is the
-# same at 8 and 16; 24 queues are more than the hardware schedules at once (35 ms per step instead of 24).
+# Default 13 = the 12 streams of a context (8 launch lanes + 4 for the traceback's full-height launches) + the null stream:
+# every context's streams then sit on 12 queues of their own, the same 12 for every context of the process.  Measured in
+# round 3 (scripts/dev/hwq_sweep.sh, gpurun_out/hwq_sweep*.txt, twice each): 12 / 13 queues give 25.7 - 25.9 ms per cDNA
+# step, 19.0 - 19.3 Iso-Seq, 35.5 - 35.6 dRNA; 16 (round 2's choice, from the days of 8 streams per context) 26.3 / 20.5 /
+# 36.0 - with more queues than a context has streams, which streams of which contexts share a queue is HIP's choice, and
+# in the Iso-Seq traceback three of ten launches then started when a neighbour had ended; 18 - 23 land between the two.
+# The end-to-end pipeline (two contexts busy at once) prefers more: 9.1 M reads/s at 12 - 13, 9.4 at 16, 9.7 at 20.
+# 24 and more are more than the hardware schedules at once: every step takes 1.7 x as long.
+DEFAULT = 13
 
 
 def _parse(raw):
@@ -23,7 +28,7 @@ def _parse(raw):
     return min(n, POOL_MAX) if n > 0 else None
 
 
-def hw_queues(default=16):
+def hw_queues(default=DEFAULT):
     """ULTRA_HW_QUEUES parsed and clamped to 1..32 (anything unparsable falls back to HIP's own default), else `default`.
     A launcher that initialises HIP before this process can (rocprofv3 does) must export BOTH GPU_MAX_HW_QUEUES and
     ULTRA_HW_QUEUES with the same value (scripts/profile_round.sh does): the first is what HIP reads, the second keeps
@@ -34,7 +39,7 @@ def hw_queues(default=16):
     return _parse(raw) or HIP_DEFAULT
 
 
-def export_hw_queues(default=16):
+def export_hw_queues(default=DEFAULT):
     """Sets GPU_MAX_HW_QUEUES for this process (call before the first HIP call) and returns the value in force."""
     n = hw_queues(default)
     os.environ["GPU_MAX_HW_QUEUES"] = str(n)
