@@ -35,7 +35,7 @@ def main():
     f, w = counters(fetch), counters(write)
     import datetime
     out = {"tag": tag, "recorded": datetime.date.today().isoformat(),
-           "command": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, GPU_MAX_HW_QUEUES=%s) -- " % os.environ.get("GPU_MAX_HW_QUEUES", "13") + ""
+           "command": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, GPU_MAX_HW_QUEUES=%s) -- " % os.environ.get("ULTRA_HW_QUEUES", "13 (ultra_amd.hwq.DEFAULT; scripts/profile_round.sh exports it under both names)") + ""
                       "python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --check 0 --e2e-rounds 0 --front-rounds 0 --micro 0 (scripts/profile_round.sh)",
            "kernels": []}
     for r in rows:
