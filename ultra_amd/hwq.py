@@ -39,8 +39,14 @@ def hw_queues(default=DEFAULT):
     return _parse(raw) or HIP_DEFAULT
 
 
-def export_hw_queues(default=DEFAULT):
-    """Sets GPU_MAX_HW_QUEUES for this process (call before the first HIP call) and returns the value in force."""
+GPU_BUDGET = 22   # queues of all processes on one GPU together: from 24 on every launch takes 1.7 x as long
+
+
+def export_hw_queues(default=DEFAULT, processes_per_gpu=1):
+    """Sets GPU_MAX_HW_QUEUES for this process (call before the first HIP call) and returns the value in force.
+    processes_per_gpu: how many such processes share the card (pc.main's consumers_per_gpu): they share GPU_BUDGET."""
     n = hw_queues(default)
+    if processes_per_gpu > 1 and os.environ.get("ULTRA_HW_QUEUES") is None:
+        n = max(HIP_DEFAULT, min(n, GPU_BUDGET // processes_per_gpu))
     os.environ["GPU_MAX_HW_QUEUES"] = str(n)
     return n

@@ -77,7 +77,8 @@ def file_IO(input_queue, reads, seeds, output_sam_buffer, outfile_name):
 def _consumer(process_id, device, input_queue, output_sam_buffer, counts_queue, args):
     os.environ["LOCAL_RANK"] = str(device)      # before anything touches HIP in this process
     from . import hwq
-    hwq.export_hw_queues()                      # a spawned child: HIP is not up yet; one hardware queue per launch lane, as benched
+    # a spawned child: HIP is not up yet.  The benched queue count, or this process's share of what one GPU schedules at once
+    hwq.export_hw_queues(processes_per_gpu=max(1, int(getattr(args, "consumers_per_gpu", 1) or 1)))
     from . import align
     align.align_single(process_id, input_queue, output_sam_buffer, counts_queue, args)
 
