@@ -44,17 +44,35 @@ __device__ __forceinline__ Cand better_lo(Cand a, Cand b)
     if (b.v > a.v || (b.v == a.v && b.idx < a.idx)) return b;
     return a;
 }
+// Wave-wide lexicographic maximum, the result in every lane.  Data-parallel-primitive moves instead of __shfl_xor (six
+// rounds of four ds_bpermute trips through the LDS crossbar per reduction, two reductions per MAM: the quadratic chainer
+// spent its time waiting for them): an inclusive scan over each row of 16 lanes (row_shr 1, 2, 4, 8; a lane without a
+// source keeps the identity, has = 0), lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15), lane 31 into rows 2 / 3
+// (row_bcast:31): lane 63 holds the maximum and is read back through the scalar unit.  The order in which candidates
+// meet does not matter: (value, index) pairs are totally ordered and distinct.
+template <bool HI, int CTRL, int ROWS> __device__ __forceinline__ Cand dpp_round(Cand c)
+{
+    Cand o;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(c.v), CTRL, ROWS, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(c.v), CTRL, ROWS, 0xf, false);
+    o.v = __hiloint2double(hi, lo);
+    o.idx = __builtin_amdgcn_update_dpp(0, c.idx, CTRL, ROWS, 0xf, false);
+    o.has = __builtin_amdgcn_update_dpp(0, c.has, CTRL, ROWS, 0xf, false);
+    return HI ? better_hi(c, o) : better_lo(c, o);
+}
 template <bool HI> __device__ __forceinline__ Cand wave_reduce(Cand c)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        Cand other;
-        other.v = __shfl_xor(c.v, o, 64);
-        other.idx = __shfl_xor(c.idx, o, 64);
-        other.has = __shfl_xor(c.has, o, 64);
-        c = HI ? better_hi(c, other) : better_lo(c, other);
-    }
-    return c;
+    c = dpp_round<HI, 0x111, 0xf>(c); // row_shr:1
+    c = dpp_round<HI, 0x112, 0xf>(c); // row_shr:2
+    c = dpp_round<HI, 0x114, 0xf>(c); // row_shr:4
+    c = dpp_round<HI, 0x118, 0xf>(c); // row_shr:8
+    c = dpp_round<HI, 0x142, 0xa>(c); // row_bcast:15 into rows 1 and 3
+    c = dpp_round<HI, 0x143, 0xc>(c); // row_bcast:31 into rows 2 and 3
+    Cand r;
+    r.v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c.v), 63), __builtin_amdgcn_readlane(__double2loint(c.v), 63));
+    r.idx = __builtin_amdgcn_readlane(c.idx, 63);
+    r.has = __builtin_amdgcn_readlane(c.has, 63);
+    return r;
 }
 
 struct ChainArgs {
@@ -550,7 +568,7 @@ static int chain_launch_device_lists(ultra_ctx *ctx, int32_t n_inst, const int32
     a.status = d_status; a.list = i_out; a.seg_first = d_first;
     const int n_launch = 1 + (ub_small > 0) + (ub_big > 0) + (ub_tree > 0);
     const bool spread = ctx->cfg.launch_lanes > 1 && n_launch > 1;
-    if (spread) ULTRA_HIP_CHECK(ctx, ultra_fork(ctx));
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_fork_at(ctx, 6));
     int li = 0;
     auto next_lane = [&]() { return spread ? ctx->lane(li++) : s; };
     if (ub_tree > 0) { // longest critical path first
@@ -583,7 +601,7 @@ static int chain_launch_device_lists(ultra_ctx *ctx, int32_t n_inst, const int32
         hipLaunchKernelGGL(chain_tiny, dim3((unsigned)((ni + 63) / 64)), dim3(64), 0, cs, a);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
-    if (spread) ULTRA_HIP_CHECK(ctx, ultra_join(ctx));
+    if (spread) ULTRA_HIP_CHECK(ctx, ultra_join_at(ctx, 7));
     return ULTRA_OK;
 }
 

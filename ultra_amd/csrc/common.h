@@ -167,7 +167,7 @@ struct AffineState {
 constexpr int kAuxStreams = 7;
 constexpr int kXtraStreams = 4;
 #ifndef ULTRA_HOSTSYNC_DEFAULT
-#define ULTRA_HOSTSYNC_DEFAULT 0x14u
+#define ULTRA_HOSTSYNC_DEFAULT 0x54u
 #endif
 constexpr int kLanes = kAuxStreams + 1;
 
@@ -202,6 +202,7 @@ struct ultra_ctx {
     bool run_active = false;     // between ultra_mam_run_begin and the end of ultra_mam_run_end
     bool tail_open = false;      // the start pass of that run has been enqueued (or the run has none)
     bool tail_has_event = false; // ... and my.ev[2] marks its end on the device
+    bool defer_tail = false;     // the run in flight was begun by ultra_mam_run_begin itself: no host waits behind the start pass
     ultra_cfg cfg;
     std::string err;
     hipDeviceProp_t prop;
@@ -239,21 +240,26 @@ static inline hipError_t ultra_join(ultra_ctx *ctx)
     return e;
 }
 
-// Experiment knob (ULTRA_DEV_HOSTSYNC = bit mask of points): at a fork the host first waits for the main stream, at a join
-// the host waits for the lanes instead of the main stream waiting for their events on the device.
-static inline unsigned ultra_hostsync_mask()
+// Host waits in front of a pass's launches (bit = point: 0 forward fork, 1 forward join, 2 start-pass fork, 3 start-pass
+// join, 4 in front of the traceback's launches, 5 traceback join, 6 chaining fork, 7 chaining join): at a fork the host
+// first waits for the main stream, at a join it waits for the lanes instead of the main stream waiting for their events on
+// the device.  Launches enqueued behind a pending event all start at once, in no order; enqueued onto a free stream one
+// after the other, the few long wavefronts go first.  Default 0x54 (measured); ULTRA_DEV_HOSTSYNC
+// overrides it for experiments.  A run begun with ultra_mam_run_begin (ctx->defer_tail) leaves out the waits behind the
+// start pass: that call promises to return with the tail in flight.
+static inline unsigned ultra_hostsync_mask(const ultra_ctx *ctx)
 {
     static const unsigned m = [] { const char *e = getenv("ULTRA_DEV_HOSTSYNC"); return e ? (unsigned)strtoul(e, nullptr, 0) : ULTRA_HOSTSYNC_DEFAULT; }();
-    return m;
+    return ctx->defer_tail ? m & ~0xF0u : m;
 }
 static inline hipError_t ultra_fork_at(ultra_ctx *ctx, int point)
 {
-    if (ultra_hostsync_mask() >> point & 1u) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) return e; }
+    if (ultra_hostsync_mask(ctx) >> point & 1u) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) return e; }
     return ultra_fork(ctx);
 }
 static inline hipError_t ultra_join_at(ultra_ctx *ctx, int point)
 {
-    if (!(ultra_hostsync_mask() >> point & 1u)) return ultra_join(ctx);
+    if (!(ultra_hostsync_mask(ctx) >> point & 1u)) return ultra_join(ctx);
     hipError_t e = hipSuccess;
     for (int i = 0; i < ctx->cfg.launch_lanes - 1 && e == hipSuccess; i++) e = hipStreamSynchronize(ctx->aux[i]);
     return e;

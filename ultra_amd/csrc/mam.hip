@@ -660,10 +660,11 @@ int mam_run_finish(ultra_ctx *ctx)
 // counts by then; the start pass, the traceback, the MAM build and the chainers are still in flight): the caller's thread
 // is free for the next batch, e.g. ultra_mam_plan_resident_behind on another context.  ultra_mam_run_end waits for the
 // device and closes the run; nothing of the results may be touched in between.
-extern "C" int ultra_mam_run_begin(ultra_ctx *ctx, double min_acc)
+static int mam_run_begin(ultra_ctx *ctx, double min_acc, bool defer_tail)
 {
     if (!ctx) return ULTRA_E_ARG;
     MamState &m = ctx->mam;
+    ctx->defer_tail = defer_tail;
     if (!m.staged || !ctx->my.staged) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_run: no staged batch");
     if (m.begun) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_run_begin: the previous run has not been closed (ultra_mam_run_end)");
     tail_state(ctx, true, false, false);
@@ -685,14 +686,17 @@ extern "C" int ultra_mam_run_end(ultra_ctx *ctx)
     MamState &m = ctx->mam;
     if (!m.begun) return ultra_fail(ctx, ULTRA_E_STATE, "ultra_mam_run_end: no run in flight (ultra_mam_run_begin)");
     m.begun = false;
+    ctx->defer_tail = false;
     const int rc = mam_run_finish(ctx);
     tail_state(ctx, false, false, false);
     return rc;
 }
 
+extern "C" int ultra_mam_run_begin(ultra_ctx *ctx, double min_acc) { return mam_run_begin(ctx, min_acc, true); }
+
 extern "C" int ultra_mam_run(ultra_ctx *ctx, double min_acc)
 {
-    const int rc = ultra_mam_run_begin(ctx, min_acc);
+    const int rc = mam_run_begin(ctx, min_acc, false);
     if (rc != ULTRA_OK) return rc;
     return ultra_mam_run_end(ctx);
 }

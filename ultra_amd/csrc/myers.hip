@@ -2861,7 +2861,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             ULTRA_HIP_CHECK(ctx, st.sorttmp.ensure(tmp_bytes + 64));
             ULTRA_HIP_CHECK(ctx, rocprim::radix_sort_pairs(st.sorttmp.p, tmp_bytes, k_in, k_out, a.hit_pairs, items_sorted, NH, 0, kTbKeyBits, s));
         }
-        if (ultra_hostsync_mask() >> 4 & 1u) ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        if (ultra_hostsync_mask(ctx) >> 4 & 1u) ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s));
         ULTRA_HIP_CHECK(ctx, hipEventSynchronize(st.ev[5])); // the counts: on the host since the start pass began
         {   // hits per group -> first sorted position of every group, then the end
             int32_t acc = 0;
