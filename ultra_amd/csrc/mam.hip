@@ -192,8 +192,13 @@ template <int VW> __device__ __forceinline__ int wave_sum_i32(int v)
 
 // VW lanes per instance: 32 (two instances share a wavefront; an instance has ~18 candidates) unless the largest
 // instance's candidate arrays would not fit LDS twice, then 64.
+// wavefronts per SIMD the register allocation aims at: 4 = 106 VGPRs, no spills.  Measured in round 3: 5 (96 VGPRs, 15
+// spilled) 1.59 -> 1.92 ms per cDNA step, 6 (80 VGPRs, 69 spilled) 2.42 ms.
+#ifndef ULTRA_MAM_WAVES
+#define ULTRA_MAM_WAVES 4
+#endif
 template <int VW>
-__global__ void __launch_bounds__(64) k_mam_build(MamArgs a)
+__global__ void __launch_bounds__(64, ULTRA_MAM_WAVES) k_mam_build(MamArgs a)
 {
     extern __shared__ int32_t lds_all[];
     const int lane = threadIdx.x % VW, part = threadIdx.x / VW;
