@@ -61,6 +61,7 @@ struct PlanArgs {
     int32_t n_inst;
     const int64_t *nam_off, *nam_part, *nam_x, *nam_y, *read_off;
     const int32_t *list; int32_t n_list;
+    const int32_t *n_list_dev; // when set: the list's length lies on the device (the grid only bounds it from above)
     int32_t *n_cand, *n_pair;
     int32_t *overflow_list, *overflow_cnt, *err, *max_cand;
     const int64_t *cand_off, *pair_off;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(64) k_plan(PlanArgs a)
 
     const int lane = threadIdx.x;
     const int inst = a.list ? a.list[blockIdx.x] : (int)blockIdx.x;
-    if (a.list ? (int)blockIdx.x >= a.n_list : inst >= a.n_inst) return;
+    if (a.list ? (int)blockIdx.x >= (a.n_list_dev ? *a.n_list_dev : a.n_list) : inst >= a.n_inst) return;
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int64_t n0 = a.nam_off[inst], n1 = a.nam_off[inst + 1];
     const int64_t lr = a.read_off[inst + 1] - a.read_off[inst];
@@ -852,7 +853,8 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     ultra_launch_presence(s, st.raw.as<uint8_t>(), read_bytes, d_mask);
     // ---- count pass (runs while the presence mask travels back) ----
     ULTRA_HIP_CHECK(ctx, m.p_ncand.ensure(NI * 4)); ULTRA_HIP_CHECK(ctx, m.p_npair.ensure(NI * 4));
-    ULTRA_HIP_CHECK(ctx, m.p_over.ensure(NI * 4 + 64)); ULTRA_HIP_CHECK(ctx, m.p_misc.ensure(64));
+    ULTRA_HIP_CHECK(ctx, m.p_over.ensure(2 * NI * 4 + 64)); // overflow list of the small capacity, then of the middle one
+    ULTRA_HIP_CHECK(ctx, m.p_misc.ensure(64));
     ULTRA_HIP_CHECK(ctx, m.p_wide.ensure((NI + 1) * 8)); ULTRA_HIP_CHECK(ctx, m.p_poff.ensure((NI + 1) * 8));
     ULTRA_HIP_CHECK(ctx, m.candoff.ensure((NI + 1) * 8));
     ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.p_misc.p, 0, 64, s));
@@ -870,7 +872,7 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     a.overflow_cnt = misc; a.err = misc + 1; a.max_cand = misc + 3;
     ULTRA_HIP_CHECK(ctx, m.p_state.ensure(NI * (size_t)plan_state_ints<128>() * 4));
     a.state = m.p_state.as<int32_t>(); a.state_stride = plan_state_ints<128>();
-    constexpr int CAP_S = 128, CAP_L = 2048; // 128 entries hold 99 % of the instances and let a CU keep twice the wavefronts in flight (the kernel is a chain of dependent loads)
+    constexpr int CAP_S = 128, CAP_M = 512, CAP_L = 2048; // 128 entries hold 99 % of the instances and let a CU keep twice the wavefronts in flight (the kernel is a chain of dependent loads)
     hipLaunchKernelGGL((k_plan<CAP_S, false>), dim3((unsigned)ni), dim3(64), plan_lds_bytes<CAP_S>(), s, a);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     uint32_t h_mask[8];
@@ -886,16 +888,25 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     if (lut_changed) ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(st.lut.p, st.h_lut, 256, hipMemcpyHostToDevice, s));
     ultra_launch_encode(s, st.raw.as<uint8_t>(), read_bytes, st.lut.as<uint8_t>(), st.seq.as<uint8_t>(), st.rseq.as<uint8_t>(), (int64_t)kArenaPad + P, st.N);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
+    // The instances that overflow the small capacity (1 % of a cDNA batch) run again at a middle one - seven wavefronts per
+    // CU instead of the one the large capacity's 83 KB of LDS leave room for (0.36 -> 0.1 ms per 262144 reads) - and what
+    // overflows that, at the large one.  The third list's length stays on the device: its launches take the second list's
+    // length as their grid and the blocks beyond the list end at once.
     const int32_t n_over = h_misc[0];
     const void *big_count = (const void *)k_plan<CAP_L, false>, *big_fill = (const void *)k_plan<CAP_L, true>;
+    PlanArgs mid = a, big = a;
     if (n_over > 0) {
         ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute(big_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds_bytes<CAP_L>()));
         ULTRA_HIP_CHECK(ctx, hipFuncSetAttribute(big_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds_bytes<CAP_L>()));
+        ULTRA_HIP_CHECK(ctx, m.p_state_mid.ensure((size_t)n_over * (size_t)plan_state_ints<CAP_M>() * 4));
         ULTRA_HIP_CHECK(ctx, m.p_state_big.ensure((size_t)n_over * (size_t)plan_state_ints<CAP_L>() * 4));
-        PlanArgs b = a;
-        b.list = a.overflow_list; b.n_list = n_over;
-        b.state = m.p_state_big.as<int32_t>(); b.state_stride = plan_state_ints<CAP_L>();
-        hipLaunchKernelGGL((k_plan<CAP_L, false>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_L>(), s, b);
+        mid.list = a.overflow_list; mid.n_list = n_over;
+        mid.state = m.p_state_mid.as<int32_t>(); mid.state_stride = plan_state_ints<CAP_M>();
+        mid.overflow_list = a.overflow_list + NI; mid.overflow_cnt = misc + 4;
+        hipLaunchKernelGGL((k_plan<CAP_M, false>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_M>(), s, mid);
+        big.list = mid.overflow_list; big.n_list = n_over; big.n_list_dev = misc + 4;
+        big.state = m.p_state_big.as<int32_t>(); big.state_stride = plan_state_ints<CAP_L>();
+        hipLaunchKernelGGL((k_plan<CAP_L, false>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_L>(), s, big);
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     // ---- CSR offsets ----
@@ -941,10 +952,12 @@ extern "C" int ultra_mam_plan_resident(ultra_ctx *ctx, const ultra_dindex *dx)
     a.read_len = m.readlen.as<int32_t>(); a.fps = m.fps.as<int64_t>(); a.lps = m.lps.as<int64_t>();
     hipLaunchKernelGGL((k_plan<CAP_S, true>), dim3((unsigned)ni), dim3(64), plan_lds_bytes<CAP_S>(), s, a);
     if (n_over > 0) {
-        PlanArgs b = a;
-        b.list = a.overflow_list; b.n_list = n_over;
-        b.state = m.p_state_big.as<int32_t>(); b.state_stride = plan_state_ints<CAP_L>();
-        hipLaunchKernelGGL((k_plan<CAP_L, true>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_L>(), s, b);
+        // the fill launches see the arrays the count launches did not have yet
+        PlanArgs fm = a, fb = a;
+        fm.list = mid.list; fm.n_list = mid.n_list; fm.state = mid.state; fm.state_stride = mid.state_stride;
+        fb.list = big.list; fb.n_list = big.n_list; fb.n_list_dev = big.n_list_dev; fb.state = big.state; fb.state_stride = big.state_stride;
+        hipLaunchKernelGGL((k_plan<CAP_M, true>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_M>(), s, fm);
+        hipLaunchKernelGGL((k_plan<CAP_L, true>), dim3((unsigned)n_over), dim3(64), plan_lds_bytes<CAP_L>(), s, fb);
     }
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_misc, misc, 16, hipMemcpyDeviceToHost, s));

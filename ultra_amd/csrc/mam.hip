@@ -394,7 +394,7 @@ void ultra_mam_free(ultra_ctx *ctx)
                       &m.cap, &m.capoff, &m.instbase, &m.scantmp, &m.flag, &m.mx, &m.my, &m.mc, &m.md, &m.mmsl, &m.mcand, &m.mval,
                       &m.nmam, &m.chainidx, &m.chainlen, &m.value, &m.lenw, &m.chainoff, &m.cx, &m.cy, &m.cc, &m.cd, &m.cmsl,
                       &m.ccand, &m.cj, &m.cval, &m.chr, &m.ckind, &m.cchr, &m.d_namoff, &m.d_readoff, &m.d_nampart, &m.d_namx, &m.d_namy,
-                      &m.p_ncand, &m.p_npair, &m.p_over, &m.p_misc, &m.p_wide, &m.p_poff, &m.p_state, &m.p_state_big};
+                      &m.p_ncand, &m.p_npair, &m.p_over, &m.p_misc, &m.p_wide, &m.p_poff, &m.p_state, &m.p_state_mid, &m.p_state_big};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : m.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (m.pinned_base) { (void)hipHostFree(m.pinned_base); m.pinned_base = nullptr; m.pinned_cap = 0; }
