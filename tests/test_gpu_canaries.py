@@ -2,8 +2,8 @@
 the library can be placed between guard regions - ULTRA_CANARIES=1 - and an out-of-bounds store of a kernel shows up as a
 damaged guard).  The mode is read once per process, so the work runs in a child process: a device-planned and a
 host-planned MAM batch with flanks and overflow-prone instances, a raw Myers batch over every size class including the
-long one, NAM chaining and the affine alignment; results are still compared with the oracle there, then every guard is
-read back.  The self-test overruns a scratch buffer by one byte and requires the check to notice."""
+long one, the MAM and NAM chainers and the affine alignment (the parity tests of those rows, called in the child);
+results are still compared with the oracle there, then every guard is read back.  The self-test overruns a scratch buffer by one byte and requires the check to notice."""
 import os
 import subprocess
 import sys
@@ -65,6 +65,20 @@ _check(ctx, helpers.make_pairs(rng, 2, (33000, 34000), (35000, 40000), kmode="re
 _check(ctx, helpers.make_pairs(rng, 300, (5, 30), (200, 1000), kmode="ref", alpha="A"))
 _check(ctx, helpers.make_pairs(rng, 60, (9, 200), (100, 500), kmode="ref"), want_ops=True)
 assert guards()[1] == 0, "myers"
+# the chainers (lane-per-instance, quadratic, n log n; MAM and NAM objective) and the affine alignment: the parity tests
+# of those rows, run here under the guards
+from tests import test_gpu_chain, test_gpu_nam, test_gpu_affine
+test_gpu_chain.test_reference_switch_rule(ctx)
+test_gpu_chain.test_lane_per_instance_kernel(ctx)
+test_gpu_chain.test_forced_quadratic_beyond_200(ctx)
+test_gpu_chain.test_tree_large_and_thresholds(ctx)
+assert guards()[1] == 0, "MAM chaining"
+test_gpu_nam.test_random_vs_oracle(ctx, 1)
+test_gpu_nam.test_random_vs_oracle(ctx, 2)
+assert guards()[1] == 0, "NAM chaining"
+test_gpu_affine.test_small_and_ragged_pairs(ctx)
+test_gpu_affine.test_read_sized_pairs(ctx)
+assert guards()[1] == 0, "affine alignment"
 nb, nd = guards()
 print("canaries ok: %%d device buffers guarded, %%d damaged" %% (nb, nd))
 ctx.close()
