@@ -2696,18 +2696,24 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     const bool use_band = ctx->cfg.banded_traceback != 0 && !want_ops && n_hits > 0 && st.S + 1 <= 32;
     if (!st.h_route) ULTRA_HIP_CHECK(ctx, hipHostMalloc((void **)&st.h_route, kRouteBytes, hipHostMallocDefault));
     int32_t *const h_info = st.h_route; // page-locked: the copy must not hold the host up
-    if (use_band) {
-        ULTRA_HIP_CHECK(ctx, st.bandinfo.ensure(256));
+    if (use_band) ULTRA_HIP_CHECK(ctx, st.bandinfo.ensure(256));
+    auto route_counts = [&]() -> int {
+        if (!use_band) return ULTRA_OK;
         ULTRA_HIP_CHECK(ctx, hipMemsetAsync(st.bandinfo.p, 0, 256, s));
         hipLaunchKernelGGL(k_band_keys<true>, dim3((unsigned)std::min<int64_t>((n_hits + 255) / 256, 1024)), dim3(256), 0, s, a, n_hits, (uint32_t *)nullptr, st.bandinfo.as<int32_t>());
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
         ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(h_info, st.bandinfo.p, (kBandBounds + kBandClasses + kNumSizeClasses) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[5], s));
-    }
-    ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
+        return ULTRA_OK;
+    };
     // ---- pass 1b: exact re-run for pairs with more end columns than first-pass slots (rare), and
     //      pass 2: start positions. ----
     const bool band_starts = ctx->cfg.banded_starts != 0 && st.total_loc > 0 && st.S + 1 <= 32;
+    // With the full set of lanes the start pass's launches leave the main stream free: the counts are taken on it beside
+    // the pass instead of in front of it (0.1 ms of an otherwise idle chip).
+    const bool counts_beside = !band_starts && ctx->cfg.launch_lanes == kLanes;
+    if (!counts_beside) { const int rrc = route_counts(); if (rrc != ULTRA_OK) return rrc; }
+    ULTRA_HIP_CHECK(ctx, hipEventRecord(st.ev[1], s));
     if (!band_starts) {
         // Full-height reverse pass: one launch per register bucket on the bucket's own lane.  A bucket's start pass
         // only reads end columns of the bucket's own pairs, so the re-run and the start pass follow each other in
@@ -2731,6 +2737,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             st.buckets[b].n_rev = blocks;
             ULTRA_HIP_CHECK(ctx, launch_mega<MODE_REV>(ctx, ab, b, nullptr, blocks));
         }
+        if (counts_beside) { const int rrc = route_counts(); if (rrc != ULTRA_OK) return rrc; }
         ULTRA_HIP_CHECK(ctx, ultra_join_at(ctx, 3));
     } else {
         // Banded reverse pass, lane per location.  The locations are sorted by (band class, columns) so that the
