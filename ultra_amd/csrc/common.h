@@ -151,7 +151,7 @@ struct MamState {
     bool has_chr = false;            // chr[] holds the chromosome id of every candidate (needed for chain_chr in the fetch)
     DevBuf chr, ckind, cchr;
     // device planner (dplan.hip): the request on the device, per-instance counts, overflow list, counters, scan scratch
-    DevBuf d_namoff, d_readoff, d_nampart, d_namx, d_namy, p_ncand, p_npair, p_over, p_misc, p_wide, p_poff, p_state, p_state_mid, p_state_big;
+    DevBuf d_namoff, d_readoff, d_nampart, d_namx, d_namy, p_ncand, p_npair, p_over, p_misc, p_wide, p_poff, p_state, p_state_mid, p_state_big, total;
     DevBuf kind, estart, estop, pair, pairc, seqlen, seqid, candoff, readlen, fps, lps, cap, capoff, instbase, scantmp, flag,
         mx, my, mc, md, mmsl, mcand, mval, nmam, chainidx, chainlen, value, lenw, chainoff, cx, cy, cc, cd, cmsl, ccand, cj, cval;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -335,19 +335,20 @@ __global__ void k_gather_i64(const int64_t *src, const int64_t *pos, int64_t *ds
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[pos[i]];
 }
-// one block: out[0] = sum of v (the batch's MAM total; the per-instance counts stay on the device until a fetch wants them)
-__global__ void __launch_bounds__(1024) k_sum_i32(const int32_t *v, int32_t n, int64_t *out)
+// out[0] += sum of v (the batch's MAM total; the per-instance counts stay on the device until a fetch wants them).  out[0]
+// is zeroed long before (behind k_mam_build's launch).  One block of 1024 threads took 0.1 ms at the very end of a run.
+__global__ void __launch_bounds__(256) k_sum_i32(const int32_t *v, int32_t n, unsigned long long *out)
 {
-    __shared__ int64_t part[1024];
-    int64_t acc = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) acc += v[i];
+    __shared__ long long part[256];
+    long long acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc += v[i];
     part[threadIdx.x] = acc;
     __syncthreads();
-    for (int d = 512; d > 0; d >>= 1) {
+    for (int d = 128; d > 0; d >>= 1) {
         if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = part[0];
+    if (threadIdx.x == 0 && part[0] != 0) atomicAdd(out, (unsigned long long)part[0]);
 }
 __global__ void k_widen(const int32_t *in, uint64_t *out, int32_t n)
 {
@@ -394,7 +395,7 @@ void ultra_mam_free(ultra_ctx *ctx)
                       &m.cap, &m.capoff, &m.instbase, &m.scantmp, &m.flag, &m.mx, &m.my, &m.mc, &m.md, &m.mmsl, &m.mcand, &m.mval,
                       &m.nmam, &m.chainidx, &m.chainlen, &m.value, &m.lenw, &m.chainoff, &m.cx, &m.cy, &m.cc, &m.cd, &m.cmsl,
                       &m.ccand, &m.cj, &m.cval, &m.chr, &m.ckind, &m.cchr, &m.d_namoff, &m.d_readoff, &m.d_nampart, &m.d_namx, &m.d_namy,
-                      &m.p_ncand, &m.p_npair, &m.p_over, &m.p_misc, &m.p_wide, &m.p_poff, &m.p_state, &m.p_state_mid, &m.p_state_big};
+                      &m.p_ncand, &m.p_npair, &m.p_over, &m.p_misc, &m.p_wide, &m.p_poff, &m.p_state, &m.p_state_mid, &m.p_state_big, &m.total};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : m.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (m.pinned_base) { (void)hipHostFree(m.pinned_base); m.pinned_base = nullptr; m.pinned_cap = 0; }
@@ -582,6 +583,8 @@ int mam_run_enqueue(ultra_ctx *ctx, double min_acc)
         ULTRA_HIP_CHECK(ctx, hipGetLastError());
     }
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[1], s));
+    ULTRA_HIP_CHECK(ctx, m.total.ensure(8));
+    ULTRA_HIP_CHECK(ctx, hipMemsetAsync(m.total.p, 0, 8, s)); // the MAM total is summed into it at the end of the run
     // ---- chaining (solver switch of classify_read_with_mams.py:560-575) ----
     // The host sorts the instances into launches by size while k_mam_build runs.  An instance cannot hold more MAMs
     // than it has slots, and the slot counts are on the host already: the launches are made up from these bounds, an
@@ -621,15 +624,14 @@ int mam_run_enqueue(ultra_ctx *ctx, double min_acc)
     hipLaunchKernelGGL(k_chain_gather, dim3((ni + 3) / 4), dim3(256), 0, s, g);
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     ULTRA_HIP_CHECK(ctx, hipEventRecord(m.ev[4], s));
-    // the scan above is done with its scratch by now (stream order): its first word takes the MAM total
-    hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(1024), 0, s, m.nmam.as<int32_t>(), ni, m.scantmp.as<int64_t>());
+    hipLaunchKernelGGL(k_sum_i32, dim3((unsigned)std::min(256, (ni + 255) / 256)), dim3(256), 0, s, m.nmam.as<int32_t>(), ni, m.total.as<unsigned long long>());
     ULTRA_HIP_CHECK(ctx, hipGetLastError());
     // the closing counts land in page-locked memory behind the slot offsets (a copy into pageable memory would hold the
     // host here until the whole run has been carried out)
     int64_t *h_close = m.pinned_base + (size_t)ni + 1;
     h_close[0] = h_close[1] = h_close[2] = 0;
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_close[0], m.chainoff.as<int64_t>() + ni, 8, hipMemcpyDeviceToHost, s));
-    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_close[1], m.scantmp.p, 8, hipMemcpyDeviceToHost, s));
+    ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_close[1], m.total.p, 8, hipMemcpyDeviceToHost, s));
     ULTRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_close[2], d_status, 4, hipMemcpyDeviceToHost, s));
     drain.dismiss();
     return ULTRA_OK;
