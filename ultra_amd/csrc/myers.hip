@@ -27,25 +27,32 @@
 namespace {
 
 enum { MODE_FWD = 0, MODE_FWD_EXACT = 1, MODE_REV = 2, MODE_NW = 3 };
+#ifndef ULTRA_BAND32W
+#define ULTRA_BAND32W 1
+#endif
+#if ULTRA_BAND32W
+enum { kBandClasses = 9, kBandFallback = 9 }; // banded traceback: 32 rows, then WB = 1, 2, 4, 6, 8, 12, 16, 32 words; class 9 = not banded
+#else
 enum { kBandClasses = 8, kBandFallback = 8 }; // banded traceback: 32 rows, then WB = 1, 2, 4, 6, 8, 12, 16 words; class 8 = not banded
+#endif
 // A lane-per-hit band kernel is bound by its longest lane (words x columns, twice): up to 2 words a hit keeps a lane
 // to itself (myers_band, and myers_band32 for the 86 % of hits with distance <= 22: half the arithmetic, checkpoint
 // bytes and LDS of the 1-word band); from 4 words on the window is split over 2 - 8 neighbouring lanes (myers_bandg),
 // which is also what lets the band reach 16 words (distance <= 1014) before the full-height kernels take over (a
 // 24-word class over 8 lanes measured slower than those for the few hits beyond).
-__host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : 16; } // classes 1..7
+__host__ __device__ constexpr int band_words(int c) { return c < 3 ? c : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : c == 7 ? 16 : 32; } // classes 1..8
 #ifndef ULTRA_BANDG_GEOM
 #define ULTRA_BANDG_GEOM 2
 #endif
 #if ULTRA_BANDG_GEOM == 0
-__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 2 : c == 4 ? 3 : c == 5 ? 4 : c == 6 ? 4 : 8; }    // lanes per hit
+__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 2 : c == 4 ? 3 : c == 5 ? 4 : c == 6 ? 4 : c == 7 ? 8 : 16; }    // lanes per hit
 #elif ULTRA_BANDG_GEOM == 1
 // one word per lane up to 8 words, two beyond: the wide bands are few, long wavefronts whose length is the length of the
 // traceback phase, and a column costs a lane about 30 instructions + 40 per word
-__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 6 : 8; }    // lanes per hit
+__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 6 : c == 7 ? 8 : 16; }    // lanes per hit
 #else
-// one word per lane throughout (12 lanes: five hits per wavefront; 16: four, a DPP row each)
-__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : 16; }    // lanes per hit
+// one word per lane throughout (12 lanes: five hits per wavefront; 16: four, a DPP row each; 32: two)
+__host__ __device__ constexpr int band_group(int c) { return c < 3 ? 1 : c == 3 ? 4 : c == 4 ? 6 : c == 5 ? 8 : c == 6 ? 12 : c == 7 ? 16 : 32; }    // lanes per hit
 #endif
 __host__ __device__ constexpr int band_rows(int c) { return c == 0 ? 32 : 64 * band_words(c); }
 #ifndef ULTRA_BAND_K0
@@ -1067,7 +1074,7 @@ __global__ void __launch_bounds__(64) myers_bandg(MyArgs a, const int32_t *items
         // value of lane + 1 as a DPP move (a VALU instruction, not a trip through the LDS crossbar): groups of 2, 4 and 8
         // lanes never straddle a row of 16, groups of 3 do
         auto from_next_lane = [&](int v) {
-            return (G == 3 || G == 6 || G == 12) ? __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
+            return (G == 3 || G == 6 || G == 12 || G == 32) ? __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
                           : __builtin_amdgcn_update_dpp(0, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
         };
         auto push_row = [&](uint32_t code1) { // the whole window moves down one row; the top lane takes the new row's code
@@ -2845,6 +2852,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
     a.nw_items = nullptr;
     bool forked = false;
     int xtra_used = 0; // streams beyond the lanes that carry a full-height launch of this run
+    bool band_xtra = false; // ... or the widest band class (the last of those streams)
     bool hook_arrived = false; // a host synchronisation has followed the caller's mid-run work on s
     int32_t full_first[kNumSizeClasses + 1], full_edmax[kNumSizeClasses];
     for (auto &v : full_first) v = 0;
@@ -2909,7 +2917,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         forked = true;
         std::vector<int64_t> v_units(units, units + kBandClasses), v_region(region, region + kBandClasses);
         std::vector<int32_t> v_first(band_first, band_first + kBandClasses + 1), v_count(h_band, h_band + kBandClasses);
-        launch_bands = [=, &st]() -> int {
+        launch_bands = [=, &st, &band_xtra]() -> int {
         const int64_t *units = v_units.data(), *region = v_region.data();
         const int32_t *band_first = v_first.data(), *h_band = v_count.data();
         size_t at = 0;
@@ -2926,6 +2934,11 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             // the 4-word class regularly started only when the 1-word class had ended (lanes i and i + 4 seem to share a
             // dispatch pipe; scripts/ubench/dispatch.hip, scripts/dev/lane_variants.sh)
             hipStream_t cs = ctx->lane(dev_tb.n == kBandClasses ? dev_tb.v[c] : ctx->cfg.launch_lanes == 8 ? (c + 4) % 8 : c);
+            if (c >= 8 && ctx->cfg.launch_lanes == kLanes) { // the ninth class: the last of the streams beyond the lanes
+                cs = ctx->xtra[kXtraStreams - 1];
+                if (!(xtra_used >> (kXtraStreams - 1) & 1)) ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(cs, ctx->fork_ev, 0));
+                band_xtra = true;
+            }
             const int64_t ni = h_band[c];
             const int WB = band_words(c);
             const size_t band_lds = (size_t)band_chunk(c) * band_rows(c) * 16; // K columns x {Pv, Ph} of the window per lane
@@ -2938,7 +2951,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
                     case 4: ULTRA_BANDG(4, 3); break;
                     case 5: ULTRA_BANDG(5, 3); break;
                     case 6: ULTRA_BANDG(6, 3); break;
-                    default: ULTRA_BANDG(7, 3); break;
+                    case 7: ULTRA_BANDG(7, 3); break;
+                    default: ULTRA_BANDG(kBandClasses - 1, 3); break;
                     }
                 } else {
                     switch (c) {
@@ -2946,7 +2960,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
                     case 4: ULTRA_BANDG(4, 5); break;
                     case 5: ULTRA_BANDG(5, 5); break;
                     case 6: ULTRA_BANDG(6, 5); break;
-                    default: ULTRA_BANDG(7, 5); break;
+                    case 7: ULTRA_BANDG(7, 5); break;
+                    default: ULTRA_BANDG(kBandClasses - 1, 5); break;
                     }
                 }
 #undef ULTRA_BANDG
@@ -3037,7 +3052,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
             const int lanes = ctx->cfg.launch_lanes;
             static const bool no_xtra = getenv("ULTRA_DEV_NO_XTRA") != nullptr;
             if (use_band && lanes == kLanes && !no_xtra) {
-                const int xi = q % kXtraStreams;
+                const int xi = q % (kXtraStreams - 1); // the last one belongs to the widest band class
                 if (!(xtra_used >> xi & 1)) { ULTRA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->xtra[xi], ctx->fork_ev, 0)); xtra_used |= 1 << xi; }
                 ULTRA_HIP_CHECK(ctx, launch_class<MODE_NW>(ctx->xtra[xi], it->cls, b, it->items, it->max_par));
                 continue;
@@ -3051,6 +3066,7 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         if (rc != ULTRA_OK) return rc;
     }
     if (forked) ULTRA_HIP_CHECK(ctx, ultra_join_at(ctx, 5));
+    if (band_xtra) xtra_used |= 1 << (kXtraStreams - 1);
     for (int xi = 0; xi < kXtraStreams; xi++)
         if (xtra_used >> xi & 1) {
             ULTRA_HIP_CHECK(ctx, hipEventRecord(ctx->xtra_ev[xi], ctx->xtra[xi]));
