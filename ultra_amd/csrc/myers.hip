@@ -2921,7 +2921,9 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         const int64_t *units = v_units.data(), *region = v_region.data();
         const int32_t *band_first = v_first.data(), *h_band = v_count.data();
         size_t at = 0;
-        for (int c = kBandClasses - 1; c >= 0; c--) {
+        static const DevList dev_order = dev_list("ULTRA_DEV_TB_ORDER"); // band classes in launch order (experiments)
+        for (int ci = 0; ci < kBandClasses; ci++) {
+            const int c = dev_order.n == kBandClasses && dev_order.v[ci] < kBandClasses ? dev_order.v[ci] : kBandClasses - 1 - ci;
             if (h_band[c] <= 0) continue;
             MyArgs b = a;
             b.tr = (ulonglong2 *)(st.trace.as<uint64_t>() + at);
