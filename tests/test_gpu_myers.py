@@ -294,3 +294,31 @@ def test_queries_beyond_32768_rows(ctx):
     got = _check(ctx, _pack([pairs[i] for i in order]))
     ed = got["ed"][np.argsort(order)]
     assert ed[0] > 1014 and ed[1] > 10000 and 0 < ed[2] <= 1014 and 0 < ed[3] <= 1014 and ed[4] > 10000 and ed[5] >= 0
+
+
+def test_more_than_2_pow_24_hits_in_one_batch(ctx):
+    """A batch with more than 2^24 hits (a million cDNA reads make 19 million): the hit offsets come out of one packed scan
+    whose hit field was 24 bits wide at first - tracebacks past it were lost without an error.  One tile of short pairs,
+    checked against the oracle, repeated over the same arena bytes: every repetition must equal the first."""
+    rng = np.random.RandomState(2024)
+    tile = helpers.make_pairs(rng, 4096, (12, 28), (24, 60), kmode="ref")
+    first = _check(ctx, tile)
+    arena, q_off, q_len, t_off, t_len, k = tile
+    keep = np.flatnonzero(first["ed"] >= 0)
+    keep = np.sort(np.concatenate([keep, np.flatnonzero(first["ed"] < 0)[:64]]))
+    n_hit = int((first["ed"][keep] >= 0).sum())
+    assert n_hit > 2000 and first["first_ins"][keep].max() > 0
+    reps = ((1 << 24) + 8192) // n_hit + 1
+    cols = [np.tile(np.asarray(c)[keep], reps) for c in (q_off, q_len, t_off, t_len, k)]
+    got = ctx.myers_hw_batch(arena, *cols)
+    T = len(keep)
+    assert int((got["ed"] >= 0).sum()) == reps * n_hit > (1 << 24)
+    for f in ("ed", "n_loc", "first_ins"):
+        assert np.array_equal(got[f].reshape(reps, T), np.broadcast_to(first[f][keep], (reps, T))), f
+    per = int(got["loc_off"][T])
+    assert int(got["loc_off"][-1]) == reps * per
+    for f in ("loc_start", "loc_end"):
+        rows = got[f][:reps * per].reshape(reps, per)
+        assert np.array_equal(rows, np.broadcast_to(rows[0], (reps, per))), f
+    a = np.concatenate([np.arange(first["loc_off"][p], first["loc_off"][p + 1]) for p in keep]).astype(np.int64)
+    assert np.array_equal(got["loc_start"][:per], first["loc_start"][a]) and np.array_equal(got["loc_end"][:per], first["loc_end"][a])

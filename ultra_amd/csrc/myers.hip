@@ -1773,14 +1773,18 @@ __global__ void k_reverse(const uint8_t *src, uint8_t *dst, int64_t n)
     if (i < n) dst[i] = src[n - 1 - i];
 }
 
-// packed[i] = (hit << 40) | nloc  so one scan yields both CSR offsets.  overflow[b] is set when a pair of register
+// packed[i] = (hit << kHitShift) | nloc  so one scan yields both CSR offsets: hits in the high half, locations in the low
+// one (location indices are int32 everywhere else; ultra_myers_run_impl refuses a batch with more).  The split was
+// 24 | 40 bits at first: a batch with more than 2^24 hits (a million cDNA reads) wrapped its hit offsets and lost
+// tracebacks without a word.  overflow[b] is set when a pair of register
 // bucket b (pairs [bucket_first[b], bucket_first[b + 1]) of the sorted order) has more end columns than first-pass slots.
+constexpr int kHitShift = 32;
 struct BucketFirst { int32_t first[6]; };
 __global__ void k_pack(const int32_t *ed, const int32_t *nloc, uint64_t *packed, int32_t n, int slot_cap, int64_t *overflow, BucketFirst bf)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        packed[i] = (ed[i] >= 0 ? (((uint64_t)1) << 40) : 0) | (uint64_t)(uint32_t)nloc[i];
+        packed[i] = (ed[i] >= 0 ? (((uint64_t)1) << kHitShift) : 0) | (uint64_t)(uint32_t)nloc[i];
         if (nloc[i] > slot_cap) { // rare; every writer stores the same value
             int b = 0;
             while (b < 4 && i >= bf.first[b + 1]) b++;
@@ -1815,14 +1819,14 @@ __global__ void k_scan_add(uint64_t *out, const uint64_t *blockoff, int64_t n)
 __global__ void k_unpack(const uint64_t *scanned, const uint64_t *packed, int64_t *loc_off, int64_t *hit_off, int32_t n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t LOW = (((uint64_t)1) << 40) - 1;
+    const uint64_t LOW = (((uint64_t)1) << kHitShift) - 1;
     if (i < n) {
         loc_off[i] = (int64_t)(scanned[i] & LOW);
-        hit_off[i] = (int64_t)(scanned[i] >> 40);
+        hit_off[i] = (int64_t)(scanned[i] >> kHitShift);
         if (i == n - 1) {
             uint64_t tot = scanned[i] + packed[i];
             loc_off[n] = (int64_t)(tot & LOW);
-            hit_off[n] = (int64_t)(tot >> 40);
+            hit_off[n] = (int64_t)(tot >> kHitShift);
         }
     }
 }
@@ -2679,6 +2683,8 @@ int ultra_myers_run_impl(ultra_ctx *ctx, bool want_ops, bool defer_sync)
         }
         st.total_loc = hb[2 * (npz - 1)]; st.total_hit = hb[2 * (npz - 1) + 1];
     }
+    if (st.total_loc > (int64_t)INT32_MAX)
+        return ultra_fail(ctx, ULTRA_E_UNSUPPORTED, "ultra_myers_run: more than 2^31 - 1 locations in one batch (" + std::to_string(st.total_loc) + "): split it");
     const size_t nl = (size_t)std::max<int64_t>(st.total_loc, 1);
     if ((int64_t)nl > loc_cap) { // first batch, or more locations than any batch before: the arrays grow, fill (again)
         ULTRA_HIP_CHECK(ctx, hipStreamSynchronize(s)); // the launch that ran ahead still writes the old arrays
