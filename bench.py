@@ -63,8 +63,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--reads", type=int, default=262144, help="reads (instances) per batch")
-    ap.add_argument("--batches", type=int, default=4, help="distinct batches per GPU (default: 4 x 262144 = 1M reads)")
+    ap.add_argument("--reads", type=int, default=1048576,
+                    help="reads (instances) per batch.  The batch is the design's free parameter: launch tails and the host round trips of a "
+                         "run are paid once per batch (measured, cDNA: 262144 reads per batch 10.4 M reads/s, 524288 11.0 M, 1048576 11.2 M)")
+    ap.add_argument("--batches", type=int, default=1,
+                    help="distinct batches per GPU (default: 1 x 1048576 = BASELINE configs[2]'s 1M reads; rounds 1-3 first ran them as 4 x 262144; "
+                         "the pipelined extra leg needs 2 or more)")
     ap.add_argument("--preset", default="ont_cdna", choices=["ont_cdna", "isoseq", "ont_drna"])
     ap.add_argument("--world", default="c3", choices=["c3", "c2", "small"])
     ap.add_argument("--rehearse", action="store_true",
@@ -562,7 +566,8 @@ def main():
             traffic = fam_traffic = None
             traffic_src = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc):
+            # ... of the default command only: another preset or batch size has no counters on record
+            if os.path.exists(pmc) and (args.preset, args.world, args.reads, args.genes) == ("ont_cdna", "c3", 1048576, 0):
                 try:
                     rec = json.load(open(pmc))
                     if rec.get("dominant_kernel") == kname:
@@ -602,7 +607,7 @@ def main():
             "config": {"workload": {"ont_cdna": "BASELINE configs[2] synthetic form (SURVEY.md 8d C3)", "isoseq": "BASELINE configs[1] synthetic form (SURVEY.md 8d C2)",
                                     "ont_drna": "BASELINE configs[4] synthetic form (SURVEY.md 8d C5)"}[args.preset] + " on world '%s': %d-gene / %d-chromosome GENCODE-shaped annotation with "
                                    "overlapping genes (%d transcripts, %d segments), %d distinct %s reads per GPU (err %.2f, lengths drawn from the "
-                                   "preset's model and cut to the transcript: mean %d bp) as %d batches of %d, reads + NAM chains + index "
+                                   "preset's model and cut to the transcript: mean %d bp) as %d batch(es) of %d, reads + NAM chains + index "
                                    "resident in HBM, one step = enumeration + alignment + chaining of one batch"
                                    % (args.world, wkw["n_genes"], wkw["n_chr"], len(w.transcripts), len(w.ref_segment_sequences), args.reads * nb, args.preset,
                                       P["err"], int(np.mean([rs.reads.size / max(len(rs), 1) for rs in sets])), nb, args.reads),

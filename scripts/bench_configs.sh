@@ -12,4 +12,4 @@ run() { # name, bench args
 }
 run default && \
 run isoseq_c2 --preset isoseq --world c2 --reads 100000 --batches 2 --micro 0 --cpu-seconds 5 && \
-run ont_drna_c3 --preset ont_drna --world c3 --reads 262144 --batches 4 --micro 0 --cpu-seconds 5
+run ont_drna_c3 --preset ont_drna --world c3 --reads 1048576 --batches 1 --micro 0 --cpu-seconds 5
