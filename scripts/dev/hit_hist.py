@@ -1,6 +1,6 @@
 """Development aid: distribution of hits over the traceback classes for the bench workload (run on the GPU box)."""
 import os
-os.environ["GPU_MAX_HW_QUEUES"] = "8"  # fixed literal, within the pool limit
+os.environ["GPU_MAX_HW_QUEUES"] = "13"  # fixed literal, within the pool limit
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -33,3 +33,13 @@ nm = np.asarray(res["n_mam"])
 print("instances", len(nm), "MAMs", int(nm.sum()), "mean", nm.mean(), "max", nm.max())
 for b in (0, 4, 8, 16, 24, 32, 48, 64, 128, 256):
     print("  n_mam <= %d: %.4f   share of sum n^2 above: %.3f" % (b, (nm <= b).mean(), (nm[nm > b].astype(np.float64) ** 2).sum() / max(1.0, (nm.astype(np.float64) ** 2).sum())))
+# hits whose insertion count follows from arithmetic: ed - |m - L| <= 1 leaves no choice (X = ed - |m - L|, I = max(m - L, 0))
+m = np.asarray(plan.packed["q_len"]).astype(np.int64)
+d = np.abs(m - L)
+free = hit & (ed - d <= 1)
+print("hits with ed - |m - L| <= 1: %d of %d (%.3f), their share of sum L %.3f, of sum L * (2 ed + 3) %.3f" % (
+    free.sum(), hit.sum(), free.sum() / hit.sum(), L[free].sum() / L[hit].sum(),
+    (L[free] * (2 * ed[free] + 3)).sum() / (L[hit] * (2 * ed[hit] + 3)).sum()))
+for lo, hi in [(0, 0), (1, 1), (2, 2), (3, 5), (6, 22)]:
+    mm = hit & (ed >= lo) & (ed <= hi)
+    print("  ed %d..%d: hits %.3f of all, free among them %.3f" % (lo, hi, mm.sum() / hit.sum(), (free & mm).sum() / max(1, mm.sum())))

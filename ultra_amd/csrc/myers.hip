@@ -62,6 +62,19 @@ __host__ __device__ constexpr int band_rows(int c) { return c == 0 ? 32 : 64 * b
 #define ULTRA_BAND_K1 16
 #endif
 __host__ __device__ constexpr int band_chunk(int c) { return c == 0 ? ULTRA_BAND_K0 : c == 1 ? ULTRA_BAND_K1 : 8; } // columns per checkpoint
+// Hits whose insertion count follows from arithmetic and need no traceback.  A global alignment of m query bases with L
+// target bases at distance ed has I - D = m - L and X + I + D = ed, so X = ed - |m - L| - 2 j for some j >= 0: when
+// ed - |m - L| <= 1 there is no choice (j = 0) and I = max(m - L, 0) whatever path the tie rule takes.  A third of the
+// cDNA hits (all with ed <= 1, 78 % of ed = 2, 12 % of ed 6 .. 22), 24 % of the 32-row band class's columns.
+// k_band_keys writes their count and sorts them behind the last real hit of their class; the band kernels skip them.
+#ifndef ULTRA_TB_ARITH
+#define ULTRA_TB_ARITH 1
+#endif
+__device__ __forceinline__ bool tb_by_arithmetic(int ed, int m, int L)
+{
+    const int d = m - L;
+    return ULTRA_TB_ARITH && ed - (d < 0 ? -d : d) <= 1;
+}
 
 struct MyArgs {
     const uint8_t *seq, *rseq;
@@ -833,7 +846,7 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
     extern __shared__ ulonglong2 band_lds[];
     ulonglong2 *col = band_lds + lane; // (column k of the chunk, word w) at col[(k * WB + w) * 64]
     for (int64_t base = gwave * 64; base < n_items; base += nwaves * 64) {
-        const bool valid = base + lane < n_items;
+        bool valid = base + lane < n_items;
         int p = 0, m = 0, L = 0, ed = 0;
         const uint8_t *q = a.seq, *t = a.seq;
         if (valid) {
@@ -845,6 +858,7 @@ __global__ void __launch_bounds__(64) myers_band(MyArgs a, const int32_t *items,
             L = a.loc_end[lo] - s0 + 1;
             q = a.seq + a.q_off[p];
             t = a.seq + a.t_off[p] + s0;
+            if (tb_by_arithmetic(ed, m, L)) { valid = false; p = m = L = ed = 0; q = t = a.seq; } // answered by k_band_keys
         }
         // Diagonals (row - column) an optimal path can touch: it starts on diagonal 0, ends on delta = m - L and
         // pays one edit per diagonal change, so |d| + |delta - d| <= ed, i.e. d in [min(0, delta) - h, max(0, delta) + h]
@@ -1046,7 +1060,7 @@ __global__ void __launch_bounds__(64) myers_bandg(MyArgs a, const int32_t *items
     extern __shared__ ulonglong2 band_lds[];
     ulonglong2 *col = band_lds; // (column k of the chunk, word w of lane l) at col[(k * WBL + w) * 64 + l]
     for (int64_t base = gwave * HITS; base < n_items; base += nwaves * HITS) {
-        const bool valid = h < HITS && base + h < n_items;
+        bool valid = h < HITS && base + h < n_items;
         int p = 0, m = 0, L = 0, ed = 0;
         const uint8_t *q = a.seq, *t = a.seq;
         if (valid) {
@@ -1058,6 +1072,7 @@ __global__ void __launch_bounds__(64) myers_bandg(MyArgs a, const int32_t *items
             L = a.loc_end[lo] - s0 + 1;
             q = a.seq + a.q_off[p];
             t = a.seq + a.t_off[p] + s0;
+            if (tb_by_arithmetic(ed, m, L)) { valid = false; p = m = L = ed = 0; q = t = a.seq; } // answered by k_band_keys
         }
         const int delta = m - L;
         const int hh = (ed - (delta < 0 ? -delta : delta)) >> 1;
@@ -1264,7 +1279,7 @@ __global__ void __launch_bounds__(64) myers_band32(MyArgs a, const int32_t *item
     extern __shared__ uint2 band32_lds[];
     uint2 *col = band32_lds + lane; // column k of the chunk at col[k * 64]
     for (int64_t base = gwave * 64; base < n_items; base += nwaves * 64) {
-        const bool valid = base + lane < n_items;
+        bool valid = base + lane < n_items;
         int p = 0, m = 0, L = 0, ed = 0;
         const uint8_t *q = a.seq, *t = a.seq;
         if (valid) {
@@ -1276,6 +1291,7 @@ __global__ void __launch_bounds__(64) myers_band32(MyArgs a, const int32_t *item
             L = a.loc_end[lo] - s0 + 1;
             q = a.seq + a.q_off[p];
             t = a.seq + a.t_off[p] + s0;
+            if (tb_by_arithmetic(ed, m, L)) { valid = false; p = m = L = ed = 0; q = t = a.seq; } // answered by k_band_keys
         }
         const int delta = m - L;
         const int hh = (ed - (delta < 0 ? -delta : delta)) >> 1;
@@ -1697,7 +1713,13 @@ __global__ void __launch_bounds__(256) k_band_keys(MyArgs a, int64_t n_hits, uin
         uint32_t c = 0;
         while (c < kBandFallback && ed > band_rows((int)c) - 10) c++;
         if (c < kBandFallback) {
-            if (!COUNT) keys[i] = c * kTbBins + (kTbBins - 1 - tb_length_bin(L));
+            if (!COUNT) {
+                const int mq = a.q_len[p];
+                if (tb_by_arithmetic(ed, mq, (int)L)) { // no traceback: behind the class's last real hit (bin of length 0)
+                    a.first_ins[p] = mq > (int)L ? mq - (int)L : 0;
+                    keys[i] = c * kTbBins + (kTbBins - 1);
+                } else keys[i] = c * kTbBins + (kTbBins - 1 - tb_length_bin(L));
+            }
             slot = (int)c; v = (int)L;
         } else {
             const uint32_t sc = size_class_of(a.q_len[p]);
