@@ -139,6 +139,14 @@ def test_banded_and_full_height_traceback_agree(ctx):
             a = _check(ctx, pairs)
             b = _check(full, pairs)
             assert np.array_equal(a["first_ins"], b["first_ins"])
+            # both kinds of hit are in the batch: insertion count by arithmetic (ed - |m - L| <= 1, no traceback in the
+            # banded mode) and by traceback
+            hit = np.flatnonzero(a["ed"] >= 0)
+            first = a["loc_off"][hit]
+            span = (a["loc_end"][first] - a["loc_start"][first] + 1).astype(np.int64)
+            free = a["ed"][hit] - np.abs(np.asarray(pairs[2])[hit].astype(np.int64) - span) <= 1
+            assert free.any() or qr[0] >= 300
+            assert (~free).any()
             assert (a["ed"] > 374).any() or qr[0] < 1300
             assert (a["ed"] > 1014).any() or qr[0] < 3600
     finally:
