@@ -200,3 +200,46 @@ def test_pipelined_batches_equal_plain_runs(ctx):
     for i in range(0, len(insts), 9):
         read, sol, _ = insts[i]
         assert _same(classify_port.classify(sol, *idx, read, None, 0.6), got[0][i])
+
+
+@pytest.mark.parametrize("preset", ["ont_cdna", "ont_drna"])
+def test_results_do_not_depend_on_the_batch(preset):
+    """Size-independent property at a bench-like size: 98 304 reads as one batch give, read by read, the values, chains and
+    MAM lists of the same reads as three batches (scripts/dev/big_batch.py does the same with a million: that is how the
+    24-bit hit offsets of the first three rounds were found)."""
+    from ultra_amd import index as native
+    from ultra_amd import lib, synth
+    w = synth.make_world(seed=20241008, **dict(synth.WORLDS["small"]))
+    rs = synth.make_reads_native(synth.FlatWorld(w), 98304, seed=7, preset=preset, threads=8)
+    ix = native.NativeIndex(*w.index())
+    dix = native.DeviceIndex(ix)
+    min_acc = synth.PRESETS[preset]["min_acc"]
+
+    def run(lo, hi):
+        c = lib.Context(0)
+        try:
+            n0, n1 = int(rs.nam_off[lo]), int(rs.nam_off[hi])
+            r0, r1 = int(rs.read_off[lo]), int(rs.read_off[hi])
+            c.mam_stage_nams(dix, np.asarray(rs.nam_off[lo:hi + 1]) - n0, np.asarray(rs.nam_part).reshape(-1, 3)[n0:n1],
+                             rs.nam_x[n0:n1], rs.nam_y[n0:n1], rs.reads[r0:r1], np.asarray(rs.read_off[lo:hi + 1]) - r0)
+            c.mam_run(min_acc)
+            return c.mam_fetch(want_all=True, want_names=True)
+        finally:
+            c.close()
+    try:
+        whole = run(0, len(rs))
+        assert int(whole["mam_off"][-1]) > 5 * len(rs)
+        step = len(rs) // 3
+        for p in range(3):
+            lo, hi = p * step, (p + 1) * step
+            part = run(lo, hi)
+            assert np.array_equal(whole["n_mam"][lo:hi], part["n_mam"])
+            assert whole["value"][lo:hi].tobytes() == part["value"].tobytes()
+            for kind, fields in (("chain", ("x", "y", "c", "d", "msl", "j", "val", "kind", "chr")), ("mam", ("x", "y", "c", "d", "msl", "val"))):
+                o = int(whole[kind + "_off"][lo])
+                assert np.array_equal(whole[kind + "_off"][lo:hi + 1] - o, part[kind + "_off"])
+                n = int(part[kind + "_off"][-1])
+                for f in fields:
+                    assert whole["%s_%s" % (kind, f)][o:o + n].tobytes() == part["%s_%s" % (kind, f)][:n].tobytes(), (kind, f, p)
+    finally:
+        dix.close(); ix.close()
