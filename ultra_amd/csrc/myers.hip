@@ -67,6 +67,9 @@ __host__ __device__ constexpr int band_chunk(int c) { return c == 0 ? ULTRA_BAND
 // ed - |m - L| <= 1 there is no choice (j = 0) and I = max(m - L, 0) whatever path the tie rule takes.  A third of the
 // cDNA hits (all with ed <= 1, 78 % of ed = 2, 12 % of ed 6 .. 22), 24 % of the 32-row band class's columns.
 // k_band_keys writes their count and sorts them behind the last real hit of their class; the band kernels skip them.
+#ifndef ULTRA_WALK_BY_COLUMN
+#define ULTRA_WALK_BY_COLUMN 1
+#endif
 #ifndef ULTRA_TB_ARITH
 #define ULTRA_TB_ARITH 1
 #endif
@@ -1377,19 +1380,57 @@ __global__ void __launch_bounds__(64) myers_band32(MyArgs a, const int32_t *item
         }
         int r = m - 1, c = L - 1, ins = 0;
         bool walking = valid;
+        // The checkpoint of the chunk below is fetched while this chunk is recomputed: taken when the chunk begins, it
+        // held the wavefront for a trip to HBM per chunk with nothing else to issue (two to three wavefronts per SIMD).
+        uint32_t nVP = 0, nVN = 0, nPL[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) nPL[k] = 0;
+        int staged = -1; // chunk whose checkpoint nVP / nVN / nPL hold (of the lanes that take part in it)
+        auto stage_checkpoint = [&](int h) {
+            staged = h;
+            if (h >= 0 && walking && h * K < L) {
+                const uint32_t *cp = CP + (int64_t)h * CPW * 64;
+                nVP = cp[0]; nVN = cp[64];
+#pragma unroll
+                for (int k = 0; k < NP; k++) nPL[k] = cp[(2 + k) * 64];
+            }
+        };
         for (int h = nchunk - 1; h >= 0; h--) {
             const int c0 = h * K;
             const bool act = walking && c0 < L;
             if (!__any(act)) continue;
+            if (staged != h) stage_checkpoint(h);
             if (act) {
-                const uint32_t *cp = CP + (int64_t)h * CPW * 64;
-                VP = cp[0]; VN = cp[64];
+                VP = nVP; VN = nVN;
 #pragma unroll
-                for (int k = 0; k < NP; k++) PL[k] = cp[(2 + k) * 64];
+                for (int k = 0; k < NP; k++) PL[k] = nPL[k];
             }
+            stage_checkpoint(h - 1);
 #pragma unroll
             for (int k = 0; k < K; k++) column(c0 + k, k, true, c0 - K);
             if (act) {
+#if ULTRA_WALK_BY_COLUMN
+                // The walk visits the columns of the chunk one after the other (a move up stays in its column, the two others
+                // go one to the left), so it is written over the columns, not over the moves: the K stored columns are read
+                // in a fixed order - loads that do not depend on the walk and are issued ahead of it - and a lane acts on
+                // column k when that is where it stands.  A run of moves up is the run of set Pv bits below the current
+                // one: counted, not stepped.  (Move by move, every step waited for an LDS read whose address the step
+                // before had produced: about half of the kernel's time at two to three wavefronts per SIMD.)
+#pragma unroll
+                for (int k = K - 1; k >= 0; k--) {
+                    const uint2 e = col[k * 64];
+                    if (r >= 0 && c == c0 + k) {
+                        const int b = (r - c + TOP - off) & 31;
+                        int ups = __clz((int)~(e.x << (31 - b))); // set bits b, b - 1, ...: that many insertions
+                        ups = ups < r + 1 ? ups : r + 1;
+                        ins += ups; r -= ups;
+                        if (r >= 0) {
+                            if (!(e.y & (1u << ((b - ups) & 31)))) r--; // not a deletion: diagonal
+                            c--;
+                        }
+                    }
+                }
+#else
                 while (r >= 0 && c >= c0) {
                     const int b = r - c + TOP - off;
                     const uint2 e = col[(c - c0) * 64];
@@ -1398,6 +1439,7 @@ __global__ void __launch_bounds__(64) myers_band32(MyArgs a, const int32_t *item
                     else if (e.y & bit) c--;
                     else { r--; c--; }
                 }
+#endif
                 if (r < 0) walking = false;
             }
         }
