@@ -141,3 +141,38 @@ def test_insertion_range_over_all_optimal_paths():
         s, e = r["locations"][0]
         lo, hi = cport.ins_range(q, t[s:e + 1], r["editDistance"])
         assert lo <= r["insertions"] <= hi
+
+
+def test_insertion_count_is_arithmetic_when_at_most_one_edit_is_free():
+    """What the banded traceback on the device relies on (csrc/myers.hip, tb_by_arithmetic): a global alignment of m query
+    bases with L target bases at distance ed has I - D = m - L and X + I + D = ed, so with ed - |m - L| <= 1 every optimal
+    path has I = max(m - L, 0) - whatever the tie rule.  Checked on the oracle's own traceback (cigar insertions of the
+    first location) over random pairs, all three kinds of edit and long gaps included; both kinds of hit must occur."""
+    from oracle import cport
+    rng = np.random.RandomState(31)
+    free = walked = 0
+    for mix, block in (((0.5, 0.3, 0.2), 0), ((1.0, 0.0, 0.0), 0), ((0.0, 0.0, 1.0), 0), ((0.45, 0.1, 0.45), 40)):
+        arena, q_off, q_len, t_off, t_len, k = helpers.make_pairs(rng, 600, (5, 160), (60, 500), planted=0.9,
+                                                                  rates=(0.0, 0.01, 0.03, 0.08, 0.2), mix=mix, block=block)
+        for p in range(len(k)):
+            q = bytes(arena[q_off[p]:q_off[p] + q_len[p]]); t = bytes(arena[t_off[p]:t_off[p] + t_len[p]])
+            r = cport.hw_align(q, t, int(k[p]))
+            ed = r["editDistance"]
+            if ed < 0:
+                continue
+            s, e = r["locations"][0]
+            m, L = len(q), e - s + 1
+            ins, num = 0, ""
+            for ch in r["cigar"]:
+                if ch.isdigit():
+                    num += ch
+                else:
+                    if ch == "I":
+                        ins += int(num)
+                    num = ""
+            if ed - abs(m - L) <= 1:
+                assert ins == max(m - L, 0), (p, ed, m, L, r["cigar"])
+                free += 1
+            else:
+                walked += 1
+    assert free > 300 and walked > 300
